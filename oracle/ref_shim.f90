@@ -1,0 +1,55 @@
+! Test infrastructure only (oracle/_ref): bind(C) entry points that forward to the
+! reference's own `module sympgpr` (python/05_tokamak/SympGPR/sympgpr.f90:12-60),
+! whose procedures take assumed-shape arrays and therefore cannot be called from C
+! directly.  This file is OUR code; the reference sources are compiled where they
+! lie under /root/reference by oracle/Makefile and are never copied into the repo.
+module sympgpr_ref_shim
+    use iso_c_binding
+    use sympgpr, only: build_K, buildKreg, guessP, calcq, calcP
+    implicit none
+contains
+
+subroutine ref_build_k(n, n0, x, y, x0, y0, hyp, K) bind(C, name="ref_build_k")
+    integer(c_int), value :: n, n0
+    real(c_double), intent(in) :: x(n), y(n), x0(n0), y0(n0), hyp(3)
+    real(c_double), intent(inout) :: K(2*n, 2*n0)
+    call build_K(x, y, x0, y0, hyp, K)
+end subroutine
+
+subroutine ref_buildkreg(n, n0, x, y, x0, y0, hyp, K) bind(C, name="ref_buildkreg")
+    integer(c_int), value :: n, n0
+    real(c_double), intent(in) :: x(n), y(n), x0(n0), y0(n0), hyp(3)
+    real(c_double), intent(inout) :: K(n, n0)
+    call buildKreg(x, y, x0, y0, hyp, K)
+end subroutine
+
+function ref_guessp(x, y, hypp, np, xtrainp, ytrainp, ztrainp, Kyinvp) &
+        bind(C, name="ref_guessp") result(r)
+    integer(c_int), value :: np
+    real(c_double), intent(in) :: x(1), y(1), hypp(3)
+    real(c_double), intent(in) :: xtrainp(np), ytrainp(np), ztrainp(np), Kyinvp(np, np)
+    real(c_double) :: r
+    r = guessP(x, y, hypp, xtrainp, ytrainp, ztrainp, Kyinvp)
+end function
+
+function ref_calcq(x, y, nt, xtrain, ytrain, hyp, Kyinv, ztrain) &
+        bind(C, name="ref_calcq") result(r)
+    integer(c_int), value :: nt
+    real(c_double), intent(in) :: x(1), y(1), hyp(3)
+    real(c_double), intent(in) :: xtrain(nt), ytrain(nt), ztrain(2*nt), Kyinv(2*nt, 2*nt)
+    real(c_double) :: r
+    r = calcq(x, y, xtrain, ytrain, hyp, Kyinv, ztrain)
+end function
+
+function ref_calcp(x, y, hyp, hypp, np, xtrainp, ytrainp, ztrainp, Kyinvp, &
+        nt, xtrain, ytrain, ztrain, Kyinv) bind(C, name="ref_calcp") result(r)
+    integer(c_int), value :: np, nt
+    real(c_double), intent(in) :: x(1), y(1), hyp(3), hypp(3)
+    real(c_double), intent(in) :: xtrainp(np), ytrainp(np), ztrainp(np), Kyinvp(np, np)
+    real(c_double), intent(in) :: xtrain(nt), ytrain(nt), ztrain(2*nt), Kyinv(2*nt, 2*nt)
+    real(c_double) :: r
+    r = calcP(x, y, hyp, hypp, xtrainp, ytrainp, ztrainp, Kyinvp, &
+        xtrain, ytrain, ztrain, Kyinv)
+end function
+
+end module sympgpr_ref_shim

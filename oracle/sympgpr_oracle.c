@@ -1,0 +1,285 @@
+/*
+ * oracle/sympgpr_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C (CPU, fp64) restatement of the SympGPR training hot path, used only as the
+ * parity checker in tests/, in __graft_entry__.smoke() and as bench.py's cpu_baseline leg.
+ * Nothing under sympgpr_amd/ may import, link or call it.
+ *
+ * Pinning: every function below is checked in tests/test_oracle.py against
+ *   (1) the known-answer inputs of the reference's own test
+ *       (python/05_tokamak/SympGPR/test_sympgpr.py:7-10,19) and
+ *   (2) golden vectors produced by the reference's own Fortran compiled from
+ *       /root/reference with amdflang (oracle/Makefile `ref` target; generator
+ *       tests/golden/make_golden.py) plus the same SciPy calls the reference makes for
+ *       the factor/solve (python/functions/func.py:165-196).
+ *
+ * Each function cites the reference file:line it restates (paths relative to
+ * /root/reference/).  Column-major everywhere, like the Fortran.
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { FAM_A = 0, FAM_B = 1, FAM_C = 2, FAM_D = 3 };
+/* which-codes of the scalar evaluator */
+enum { W_KERN = 0, W_DXDX0 = 1, W_DYDY0 = 2, W_DXDY0 = 3 };
+
+/* ---- scalar kernels ------------------------------------------------------------------
+ * Family A  periodic(q) x SE(P), product:
+ *     python/05_tokamak/SympGPR/kernels.f90:1-11 (kern), :58-70 (d2kdxdx0),
+ *     :71-82 (d2kdydy0), :83-94 (d2kdxdy0)   [5 md5-identical copies in the tree]
+ * Family B  periodic(q) + SE(P), sum (explicit map):
+ *     python/01_pendulum/explicit/kernels_sum.f90:1-11, :58-67, :68-78, :79-88 (== 0)
+ * Family C  SE x SE:
+ *     python/03_henon_heiles/kernels_sq.f90:1-10, :55-65, :66-76, :77-87
+ * Family D  periodic with free period p (7-argument functions, l = (lx, ly, p)):
+ *     python/01_pendulum/implicit_period_unknown/kernels.f90:1-12, :63-75, :76-88, :89-101
+ * The expressions keep the operation order of the generated Fortran.
+ */
+static double sq(double v) { return v * v; }
+
+double orc_scalar(int fam, int which, double x_a, double y_a, double x_b, double y_b,
+                  double lx, double ly, double p)
+{
+    const double lx2 = lx * lx, ly2 = ly * ly;
+    switch (fam) {
+    case FAM_A: {
+        const double s = sin(0.5 * x_a - 0.5 * x_b), c = cos(0.5 * x_a - 0.5 * x_b);
+        const double dy = y_a - y_b;
+        switch (which) {
+        case W_KERN:
+            return exp(-0.5 * sq(dy) / ly2 - 0.5 * sq(s) / lx2);
+        case W_DXDX0:
+            return 0.25 * (lx2 * cos(1.0 * x_a - 1.0 * x_b) - sq(s) * sq(c)) *
+                   exp(0.5 * (-lx2 * sq(dy) - ly2 * sq(s)) / (lx2 * ly2)) / (lx2 * lx2);
+        case W_DYDY0:
+            return 1.0 * (ly2 - sq(dy)) *
+                   exp(0.5 * (-lx2 * sq(dy) - ly2 * sq(s)) / (lx2 * ly2)) / (ly2 * ly2);
+        case W_DXDY0:
+            return -0.5 * dy * exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(s)) / (lx2 * ly2)) * s * c /
+                   (lx2 * ly2);
+        }
+        break;
+    }
+    case FAM_B: {
+        const double s = sin(0.5 * x_a - 0.5 * x_b), c = cos(0.5 * x_a - 0.5 * x_b);
+        const double ey = exp((-0.5 * sq(y_a) + 1.0 * y_a * y_b - 0.5 * sq(y_b)) / ly2);
+        switch (which) {
+        case W_KERN:
+            return ey + exp(-0.5 * sq(s) / lx2);
+        case W_DXDX0:
+            return (0.25 * lx2 * cos(1.0 * x_a - 1.0 * x_b) - 0.25 * sq(s) * sq(c)) *
+                   exp(-0.5 * sq(s) / lx2) / (lx2 * lx2);
+        case W_DYDY0:
+            return 1.0 * (ly2 - sq(y_a - y_b)) * ey / (ly2 * ly2);
+        case W_DXDY0:
+            return 0.0;
+        }
+        break;
+    }
+    case FAM_C: {
+        const double dx = x_a - x_b, dy = y_a - y_b;
+        switch (which) {
+        case W_KERN:
+            return exp(-0.5 * sq(dy) / ly2 - 0.5 * sq(dx) / lx2);
+        case W_DXDX0:
+            return 1.0 * (lx2 - sq(dx)) *
+                   exp(0.5 * (-lx2 * sq(dy) - ly2 * sq(dx)) / (lx2 * ly2)) / (lx2 * lx2);
+        case W_DYDY0:
+            return 1.0 * (ly2 - sq(dy)) *
+                   exp(0.5 * (-lx2 * sq(dy) - ly2 * sq(dx)) / (lx2 * ly2)) / (ly2 * ly2);
+        case W_DXDY0:
+            return -1.0 * dx * dy * exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(dx)) / (lx2 * ly2)) /
+                   (lx2 * ly2);
+        }
+        break;
+    }
+    case FAM_D: {
+        const double s = sin(p * (x_a - x_b)), c = cos(p * (x_a - x_b));
+        const double dy = y_a - y_b;
+        switch (which) {
+        case W_KERN:
+            return exp(-0.5 * sq(dy) / ly2 - 0.5 * sq(s) / lx2);
+        case W_DXDX0:
+            return 1.0 * sq(p) * (lx2 * cos(2.0 * p * (x_a - x_b)) - sq(s) * sq(c)) *
+                   exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(s)) / (lx2 * ly2)) / (lx2 * lx2);
+        case W_DYDY0:
+            return 1.0 * (ly2 - sq(dy)) *
+                   exp(0.5 * (-lx2 * sq(dy) - ly2 * sq(s)) / (lx2 * ly2)) / (ly2 * ly2);
+        case W_DXDY0:
+            return -1.0 * p * dy * exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(s)) / (lx2 * ly2)) * s *
+                   c / (lx2 * ly2);
+        }
+        break;
+    }
+    }
+    return NAN;
+}
+
+/* hyp layout of the reference: (lx, ly, sig) for A/B/C (sympgpr.f90:17, func.py:47-48
+ * `l = hyp[:-1]; sig = hyp[-1]`), (lx, ly, p, sig) for D
+ * (01_pendulum/implicit_period_unknown/func.py:18-19,45-46). */
+static void split_hyp(int fam, const double *hyp, double *lx, double *ly, double *p, double *sig)
+{
+    *lx = hyp[0];
+    *ly = hyp[1];
+    if (fam == FAM_D) { *p = hyp[2]; *sig = hyp[3]; }
+    else              { *p = 0.0;    *sig = hyp[2]; }
+}
+
+/* build_K: python/05_tokamak/SympGPR/sympgpr.f90:12-38 (== pure-Python loop of
+ * python/01_pendulum/implicit/func.py:44-64).  K is (2n x 2n0), column-major, leading
+ * dimension ldk; a = column ("0") point, b = row point; K *= sig AFTER the fill.
+ * `threads` <= 1 reproduces the reference's single-threaded j-outer/i-inner loop order. */
+int orc_build_k(int fam, int n, int n0, const double *x, const double *y, const double *x0,
+                const double *y0, const double *hyp, double *K, size_t ldk, int threads)
+{
+    double lx, ly, p, sig;
+    split_hyp(fam, hyp, &lx, &ly, &p, &sig);
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int j = 0; j < n0; ++j) {
+        for (int i = 0; i < n; ++i) {
+            K[i + (size_t)j * ldk] = orc_scalar(fam, W_DXDX0, x0[j], y0[j], x[i], y[i], lx, ly, p);
+            K[n + i + (size_t)j * ldk] = orc_scalar(fam, W_DXDY0, x0[j], y0[j], x[i], y[i], lx, ly, p);
+            K[i + (size_t)(n0 + j) * ldk] = orc_scalar(fam, W_DXDY0, x0[j], y0[j], x[i], y[i], lx, ly, p);
+            K[n + i + (size_t)(n0 + j) * ldk] = orc_scalar(fam, W_DYDY0, x0[j], y0[j], x[i], y[i], lx, ly, p);
+        }
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int j = 0; j < 2 * n0; ++j)
+        for (int i = 0; i < 2 * n; ++i) K[i + (size_t)j * ldk] *= sig; /* sympgpr.f90:37 */
+    return 0;
+}
+
+/* buildKreg: python/05_tokamak/SympGPR/sympgpr.f90:40-60. K is (n x n0). */
+int orc_buildkreg(int fam, int n, int n0, const double *x, const double *y, const double *x0,
+                  const double *y0, const double *hyp, double *K, size_t ldk, int threads)
+{
+    double lx, ly, p, sig;
+    split_hyp(fam, hyp, &lx, &ly, &p, &sig);
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int j = 0; j < n0; ++j)
+        for (int i = 0; i < n; ++i)
+            K[i + (size_t)j * ldk] =
+                sig * orc_scalar(fam, W_KERN, x0[j], y0[j], x[i], y[i], lx, ly, p); /* :54-59 */
+    return 0;
+}
+
+/* Ky = K + |sig2n| I : python/functions/func.py:183,192 */
+void orc_add_noise(int n, double *K, size_t ldk, double sig2n)
+{
+    for (int i = 0; i < n; ++i) K[i + (size_t)i * ldk] += fabs(sig2n);
+}
+
+/* Lower Cholesky, in place, column-major (what scipy.linalg.cholesky(Ky, lower=True)
+ * -> LAPACK dpotrf computes at python/functions/func.py:166,184,193).  Left-looking
+ * column (dpotf2-style) algorithm; the strict upper triangle is zeroed like SciPy does.
+ * Returns 0, or k>0 if the leading minor of order k is not positive definite
+ * (SciPy raises LinAlgError there). */
+int orc_cholesky_lower(int n, double *A, size_t lda)
+{
+    for (int j = 0; j < n; ++j) {
+        double *cj = A + (size_t)j * lda;
+        for (int k = 0; k < j; ++k) {
+            const double *ck = A + (size_t)k * lda;
+            const double ljk = ck[j];
+            if (ljk != 0.0)
+                for (int i = j; i < n; ++i) cj[i] -= ck[i] * ljk;
+        }
+        const double d = cj[j];
+        if (!(d > 0.0)) return j + 1;
+        const double r = sqrt(d);
+        cj[j] = r;
+        for (int i = j + 1; i < n; ++i) cj[i] /= r;
+    }
+    for (int j = 1; j < n; ++j)
+        for (int i = 0; i < j; ++i) A[i + (size_t)j * lda] = 0.0;
+    return 0;
+}
+
+/* alpha = L^-T (L^-1 b): python/functions/func.py:174-177 (two dtrtrs). nrhs columns. */
+void orc_solve_cholesky(int n, const double *L, size_t ldl, double *B, size_t ldb, int nrhs)
+{
+    for (int r = 0; r < nrhs; ++r) {
+        double *b = B + (size_t)r * ldb;
+        for (int j = 0; j < n; ++j) { /* forward, column-oriented */
+            b[j] /= L[j + (size_t)j * ldl];
+            const double bj = b[j];
+            const double *cj = L + (size_t)j * ldl;
+            for (int i = j + 1; i < n; ++i) b[i] -= cj[i] * bj;
+        }
+        for (int j = n - 1; j >= 0; --j) { /* backward with L^T: dot products */
+            const double *cj = L + (size_t)j * ldl;
+            double s = b[j];
+            for (int i = j + 1; i < n; ++i) s -= cj[i] * b[i];
+            b[j] = s / cj[j];
+        }
+    }
+}
+
+/* nll = 0.5 y.alpha + sum log diag L : python/functions/func.py:186,195 */
+double orc_nll(int n, const double *L, size_t ldl, const double *y, const double *alpha)
+{
+    double q = 0.0, ld = 0.0;
+    for (int i = 0; i < n; ++i) { q += y[i] * alpha[i]; ld += log(L[i + (size_t)i * ldl]); }
+    return 0.5 * q + ld;
+}
+
+/* Whole fit as nll_chol does it (python/functions/func.py:189-196): build_K on (x,x),
+ * add |sig2n| I, factor, solve.  x,y: the n_pts training inputs; z: 2*n_pts targets.
+ * K (2n x 2n, ld 2n) is caller scratch and holds L on return.  Returns the potrf info. */
+int orc_fit(int fam, int n_pts, const double *x, const double *y, const double *z,
+            const double *hyp, double sig2n, double *K, double *alpha, double *nll, int threads)
+{
+    const int n = 2 * n_pts;
+    orc_build_k(fam, n_pts, n_pts, x, y, x, y, hyp, K, (size_t)n, threads);
+    orc_add_noise(n, K, (size_t)n, sig2n);
+    int info = orc_cholesky_lower(n, K, (size_t)n);
+    if (info) return info;
+    memcpy(alpha, z, sizeof(double) * (size_t)n);
+    orc_solve_cholesky(n, K, (size_t)n, alpha, (size_t)n, 1);
+    if (nll) *nll = orc_nll(n, K, (size_t)n, z, alpha);
+    return 0;
+}
+
+/* Prediction rows with cached alpha (the O(n) form of sympgpr.f90:75-86 `calcq` and of
+ * `target` at :112-124; the reference recomputes matmul(Kyinv, ztrain) = alpha per call).
+ * For m test points (q_k, P_k):  out_p[k] = Kstar(1,:).alpha, out_q[k] = Kstar(2,:).alpha
+ * with Kstar = build_K(x=q_k, y=P_k, x0=xtrain, y0=ytrain)  (2 x 2N0). */
+void orc_predict_rows(int fam, int m, const double *q, const double *P, int n0,
+                      const double *xtrain, const double *ytrain, const double *hyp,
+                      const double *alpha, double *out_p, double *out_q)
+{
+    double lx, ly, p, sig;
+    split_hyp(fam, hyp, &lx, &ly, &p, &sig);
+    for (int k = 0; k < m; ++k) {
+        double r1 = 0.0, r2 = 0.0;
+        for (int j = 0; j < n0; ++j) {
+            const double kxx = sig * orc_scalar(fam, W_DXDX0, xtrain[j], ytrain[j], q[k], P[k], lx, ly, p);
+            const double kxy = sig * orc_scalar(fam, W_DXDY0, xtrain[j], ytrain[j], q[k], P[k], lx, ly, p);
+            const double kyy = sig * orc_scalar(fam, W_DYDY0, xtrain[j], ytrain[j], q[k], P[k], lx, ly, p);
+            r1 += kxx * alpha[j] + kxy * alpha[n0 + j];
+            r2 += kxy * alpha[j] + kyy * alpha[n0 + j];
+        }
+        out_p[k] = r1;
+        out_q[k] = r2;
+    }
+}
+
+/* Regular-GP prediction with cached alpha_p (sympgpr.f90:62-73 `guessP`). */
+void orc_predict_reg(int fam, int m, const double *q, const double *P, int n0,
+                     const double *xtrain, const double *ytrain, const double *hyp,
+                     const double *alpha, double *out)
+{
+    double lx, ly, p, sig;
+    split_hyp(fam, hyp, &lx, &ly, &p, &sig);
+    for (int k = 0; k < m; ++k) {
+        double r = 0.0;
+        for (int j = 0; j < n0; ++j)
+            r += sig * orc_scalar(fam, W_KERN, xtrain[j], ytrain[j], q[k], P[k], lx, ly, p) * alpha[j];
+        out[k] = r;
+    }
+}

@@ -1,0 +1,121 @@
+"""CPU suite: pins the oracle (oracle/sympgpr_oracle.c) against the reference's own test
+inputs (python/05_tokamak/SympGPR/test_sympgpr.py:7-10,19-45) and against golden vectors
+generated from the reference's compiled Fortran + SciPy (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+FAMS = "ABCD"
+
+
+@pytest.fixture(scope="module")
+def ka(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "known_answer.json")))
+
+
+@pytest.fixture(scope="module")
+def gram(golden_dir):
+    return np.load(os.path.join(golden_dir, "gram.npz"))
+
+
+@pytest.fixture(scope="module")
+def fits(golden_dir):
+    return np.load(os.path.join(golden_dir, "fits.npz"))
+
+
+def test_known_answer_build_K(oracle, ka):
+    # same tolerance as the reference's own equivalence test (test_sympgpr.py:26,35,44)
+    K = oracle.build_K("A", ka["x"], ka["y"], ka["x0"], ka["y0"], ka["hyp"])
+    assert K.shape == (6, 4) and K.flags.f_contiguous
+    np.testing.assert_allclose(K, np.array(ka["build_K_6x4"]), rtol=1e-12, atol=1e-12)
+    # sanity rows quoted in SURVEY.md 8(c): diag of q-block sig/4/lx^2, of P-block sig/ly^2
+    assert K[0, 0] == pytest.approx(0.4, abs=1e-15) and K[3, 2] == pytest.approx(0.1, abs=1e-15)
+    G = oracle.buildKreg("A", ka["x"], ka["y"], ka["x0"], ka["y0"], ka["hyp"])
+    np.testing.assert_allclose(G, np.array(ka["buildKreg_3x2"]), rtol=1e-12, atol=1e-12)
+    G1 = oracle.buildKreg("A", ka["x"][:1], ka["y"][:1], ka["x0"], ka["y0"], ka["hyp"])
+    np.testing.assert_allclose(G1, np.array(ka["buildKreg_1x2"]), rtol=1e-12, atol=1e-12)
+
+
+def test_known_answer_fit(oracle, ka):
+    f = ka["fit6"]
+    alpha, nll, L = oracle.fit("A", ka["x"], ka["y"], f["z"], ka["hyp"], f["sig2n"])
+    np.testing.assert_allclose(alpha, f["alpha"], rtol=1e-12)
+    assert nll == pytest.approx(f["nll"], rel=1e-13)
+    assert np.all(np.triu(L, 1) == 0.0)
+
+
+def test_known_answer_predict_rows(oracle, ka):
+    """calcq / guessP of the reference recompute alpha = Kyinv @ ztrain per call
+    (sympgpr.f90:72,85); with that alpha handed in, the row forms must agree."""
+    alpha = np.array(ka["Kyinv"]) @ np.array(ka["ztrain"])
+    op, oq = oracle.predict_rows("A", ka["x"][:1], ka["y"][:1], ka["x0"], ka["y0"], ka["hyp"], alpha)
+    assert oq[0] == pytest.approx(ka["calcQ"], rel=1e-12)
+    alphap = np.array(ka["Kyinvp"]) @ np.array(ka["ztrainp"])
+    g = oracle.predict_reg("A", ka["x"][:1], ka["y"][:1], ka["x0"], ka["y0"], ka["hypp"], alphap)
+    assert g[0] == pytest.approx(ka["guessP"], rel=1e-12)
+    # calcP's fixed point: f(P) = pGP(q, P) - p + P = 0 (sympgpr.f90:112-124), hybrd1 tol 1e-13
+    P = ka["calcP"]
+    op, _ = oracle.predict_rows("A", ka["x"][:1], [P], ka["x0"], ka["y0"], ka["hyp"], alpha)
+    assert abs(op[0] - ka["y"][0] + P) < 1e-11
+
+
+@pytest.mark.parametrize("fam", FAMS)
+@pytest.mark.parametrize("tag", ["sq8", "sq64", "rect5x7", "row1x9", "col9x1"])
+def test_gram_golden(oracle, gram, fam, tag):
+    g = lambda k: gram[f"{fam}_{tag}_{k}"]
+    K = oracle.build_K(fam, g("x"), g("y"), g("x0"), g("y0"), g("hyp"))
+    scale = np.abs(g("K")).max()
+    assert np.abs(K - g("K")).max() <= 4e-16 * scale
+    G = oracle.buildKreg(fam, g("x"), g("y"), g("x0"), g("y0"), g("hyp"))
+    assert np.abs(G - g("Kreg")).max() <= 4e-16 * np.abs(g("Kreg")).max()
+    if tag.startswith("sq") and fam != "B":
+        # exact symmetry; family B's exp((-ya^2/2 + ya*yb - yb^2/2)/ly^2)
+        # (kernels_sum.f90:9) is not rounding-symmetric under a<->b
+        assert np.abs(K - K.T).max() == 0.0
+    if fam == "B":
+        n, n0 = len(g("x")), len(g("x0"))
+        assert np.all(K[n:, :n0] == 0.0) and np.all(K[:n, n0:] == 0.0)
+
+
+def test_gram_empty(oracle):
+    K = oracle.build_K("A", [], [], [], [], [0.5, 2.0, 0.4])
+    assert K.shape == (0, 0)
+
+
+def test_threads_same_result(oracle, gram):
+    g = lambda k: gram[f"A_sq64_{k}"]
+    K1 = oracle.build_K("A", g("x"), g("y"), g("x0"), g("y0"), g("hyp"), threads=1)
+    K4 = oracle.build_K("A", g("x"), g("y"), g("x0"), g("y0"), g("hyp"), threads=4)
+    assert np.array_equal(K1, K4)
+
+
+@pytest.mark.parametrize("tag", ["A_N32", "A_N128", "A_N512", "C_N32", "C_N128", "C_N512", "A_driver20"])
+def test_fit_golden(oracle, fits, tag):
+    g = lambda k: fits[f"{tag}_{k}"]
+    alpha, nll, L = oracle.fit(tag[0], g("q"), g("P"), g("z"), g("hyp"), float(g("sig2n")))
+    cond = float(g("cond"))
+    # tolerance budget: both solves are backward stable -> relative difference <~ cond * eps * c
+    tol = max(1e-10, 50 * cond * 2.2e-16)
+    rel = np.linalg.norm(alpha - g("alpha_hp")) / np.linalg.norm(g("alpha_hp"))
+    assert rel < tol, (rel, cond)
+    rel2 = np.linalg.norm(alpha - g("alpha")) / np.linalg.norm(g("alpha"))
+    assert rel2 < tol
+    assert nll == pytest.approx(float(g("nll")), rel=max(1e-11, tol))
+    np.testing.assert_allclose(np.diag(L), g("Ldiag"), rtol=1e-10)
+
+
+def test_not_positive_definite(oracle):
+    with pytest.raises(np.linalg.LinAlgError):
+        oracle.cholesky(np.array([[1.0, 2.0], [2.0, 1.0]]))
+
+
+def test_multi_rhs_solve(oracle, fits):
+    g = lambda k: fits[f"A_N32_{k}"]
+    K = oracle.build_K("A", g("q"), g("P"), g("q"), g("P"), g("hyp"))
+    Ky = K + float(g("sig2n")) * np.eye(64)
+    L = oracle.cholesky(Ky)
+    B = np.random.default_rng(0).standard_normal((64, 5))
+    X = oracle.solve_cholesky(L, B)
+    assert np.abs(Ky @ X - B).max() < 1e-10
