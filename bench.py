@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- SympGPR training hot path on MI355X: Gram build + Cholesky + alpha.
+
+One "step" = one pass of the hot path over one synthetic training set resident in HBM:
+    Ky = build_K(x, x) + |sig2n| I   ->   L = cholesky(Ky)   ->   alpha = L^-T L^-1 z, nll
+(the body of nll_chol, python/functions/func.py:189-196 of the reference).
+
+Metric (BASELINE.json): "Gram-build GB/s + Cholesky fp64 TFLOP/s at N=65536 d=2;
+|alpha-alpha_ref|/|alpha_ref|".  d = 2 input coordinates (q, P) per training point, so the
+matrix order is n = 2N = 131072 (137 GB in place; see SURVEY.md 8 preamble).  `value` is the
+whole-step Cholesky-equivalent rate (n^3/3 flop / wall time of the whole step, build and solve
+included); the per-stage rates are reported beside it.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--n-pts N] [--family A]
+        N > 1 is launched by torch.distributed.run, one rank per GPU.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+MFMA_F64_PEAK_TF = 78.6   # MI355X fp64 matrix peak, vendor spec
+
+
+def synth(n_pts, seed=1234):
+    """q ~ U(0, 2pi), P ~ U(-3, 3), z ~ N(0,1); l = 2 sqrt(12 pi / N), sig = 1,
+    sig2n = 1e-2 / l^2 (bounded condition number)."""
+    rng = np.random.default_rng(seed)
+    q = rng.uniform(0, 2 * np.pi, n_pts)
+    P = rng.uniform(-3, 3, n_pts)
+    z = rng.standard_normal(2 * n_pts)
+    l = 2.0 * np.sqrt(12 * np.pi / n_pts)
+    return q, P, z, np.array([l, l, 1.0]), 1e-2 / l**2
+
+
+def cpu_baseline(family, n_pts_sample):
+    """The reference's own Fortran build_K (oracle/_ref, 1 thread -- the reference is
+    single-threaded) + the SciPy calls of func.py:193-194, on a bounded sample of the same
+    synthetic workload.  Falls back to the C port (oracle/liboracle.so) when _ref is absent."""
+    import scipy.linalg
+    from oracle.oracle import Oracle, Ref
+    q, P, z, hyp, s2 = synth(n_pts_sample)
+    n = 2 * n_pts_sample
+    kind = "reference" if (Ref.available() and family in "AC") else "port"
+    t0 = time.perf_counter()
+    if kind == "reference":
+        K = Ref().build_K(family, q, P, q, P, hyp)
+    else:
+        K = Oracle().build_K(family, q, P, q, P, hyp, threads=1)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    K[np.diag_indices(n)] += abs(s2)
+    Lf = scipy.linalg.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    t_chol = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    alpha = scipy.linalg.solve_triangular(
+        Lf.T, scipy.linalg.solve_triangular(Lf, z, lower=True, check_finite=False),
+        lower=False, check_finite=False)
+    t_solve = time.perf_counter() - t0
+    total = t_build + t_chol + t_solve
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    return {
+        "value": (n**3 / 3.0) / total / 1e12, "unit": "TFLOP/s", "cores": int(blas_threads),
+        "kind": kind,
+        "sample": "n=%d (N=%d pts): build_K 1 thread %.2fs = %.3f GB/s; scipy cholesky %d threads %.2fs = "
+                  "%.1f GFLOP/s; 2x solve_triangular %.2fs" % (n, n_pts_sample, t_build, 8.0 * n * n / t_build / 1e9,
+                                                               blas_threads, t_chol, n**3 / 3.0 / t_chol / 1e9, t_solve),
+        "gram_gb_s": 8.0 * n * n / t_build / 1e9, "chol_tflops": n**3 / 3.0 / t_chol / 1e12,
+        "host_cpus": os.cpu_count(),
+    }, alpha, (q, P, z, hyp, s2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2N)")
+    ap.add_argument("--family", default="A")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="N of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--full-matrix", action="store_true", help="build all of K, not only the lower triangle")
+    args = ap.parse_args()
+
+    import torch
+    import sympgpr_amd
+    from sympgpr_amd import _lib as L
+    from sympgpr_amd.fit import SympFit
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
+    if sympgpr_amd.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libsympgpr_hip.so has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    lib = L.load_library()
+    L.check(lib.sgpr_set_device(local_rank))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world > 1:
+        from sympgpr_amd.dist_bench import run_distributed
+        return run_distributed(args, rank, local_rank, world)
+
+    n_pts = args.n_pts
+    n = 2 * n_pts
+    q, P, z, hyp, s2 = synth(n_pts)
+    fit = SympFit(args.family, q, P, z, hyp, s2, lower_only=not args.full_matrix)
+
+    for _ in range(args.warmup):
+        fit.run()
+    stage = np.zeros(3)
+    prof = np.zeros(8)
+    barrier()
+    L.check(lib.sgpr_profile_begin())
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fit.run()
+        stage += np.array(fit.stage_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    L.check(lib.sgpr_profile_end(L.dptr(prof)))
+    stage /= max(args.steps, 1)
+    ms_per_step = dt / args.steps * 1e3
+
+    # parity evidence at full size: Ky alpha == z through the independent K*-row kernel
+    a = fit.alpha()
+    m = min(n_pts, 2048)
+    idx = np.random.default_rng(0).choice(n_pts, m, replace=False)
+    op, oq = fit.predict_rows(q[idx], P[idx])
+    r = np.concatenate([op + s2 * a[idx] - z[idx], oq + s2 * a[n_pts + idx] - z[n_pts + idx]])
+    resid = float(np.linalg.norm(r) / np.linalg.norm(np.concatenate([z[idx], z[n_pts + idx]])))
+    nll = fit.nll()
+    fit.close()
+
+    gram_bytes = 8.0 * n * (n + 1) / 2 if not args.full_matrix else 8.0 * n * n
+    chol_flop = n**3 / 3.0
+    out = {
+        "metric": "Gram-build GB/s + Cholesky fp64 TFLOP/s at N=65536 d=2; |alpha-alpha_ref|/|alpha_ref|",
+        "value": chol_flop / (ms_per_step * 1e-3) / 1e12,
+        "unit": "TFLOP/s (n^3/3 flop over the whole step: Gram build + Cholesky + solve)",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "synthetic d=2 N=%d: matrix order n=%d (%.1f GB fp64), family %s, "
+                               "l=2*sqrt(12pi/N), sig2n=1e-2/l^2" % (n_pts, n, 8.0 * n * n / 1e9, args.family),
+                   "n_pts": n_pts, "order_n": n, "triangle": "full" if args.full_matrix else "lower"},
+        "gram_gb_s": gram_bytes / (stage[0] * 1e-3) / 1e9,
+        "gram_ms": stage[0],
+        "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12,
+        "chol_ms": stage[1],
+        "solve_ms": stage[2],
+        "residual_Ky_alpha_minus_z": resid,
+        "nll": nll,
+    }
+    big_n, big_flop, big_ms = prof[0], prof[1], prof[2]
+    if big_n > 0 and big_ms > 0:
+        ach = big_flop / (big_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (fp64 MFMA trailing update)",
+                           "achieved": ach, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": ach / MFMA_F64_PEAK_TF, "traffic": None,
+                           "launches": int(big_n), "flop_per_launch": big_flop / big_n,
+                           "avg_launch_ms": big_ms / big_n,
+                           "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}
+    out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel", "achieved": out["gram_gb_s"],
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["gram_gb_s"] / HBM_PEAK_GBS,
+                            "traffic": None}
+    if args.cpu_sample > 0:
+        cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family, args.cpu_sample)
+        with SympFit(args.family, qs, Ps, zs, hs, s2s) as fs:
+            a_gpu = fs.run().alpha()
+        out["alpha_rel_err"] = float(np.linalg.norm(a_gpu - a_ref) / np.linalg.norm(a_ref))
+        out["alpha_rel_err_at"] = "n=%d vs the CPU baseline's solve" % (2 * args.cpu_sample)
+        out["cpu_baseline"] = cb
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

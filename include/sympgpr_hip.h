@@ -1,0 +1,167 @@
+/*
+ * sympgpr_hip.h -- C ABI of libsympgpr_hip.so, the MI355X (gfx950) implementation of
+ * SympGPR's GP training core.  Plain C: pointers, sizes, ints; no torch / C++ types.
+ *
+ * This is the drop-in boundary for the ONE hot path of redmod-team/SympGPR:
+ *   build_K / buildKreg            (python/05_tokamak/SympGPR/sympgpr.f90:12-60, the f2py
+ *                                   object `sympgpr.build_k`, `sympgpr.buildkreg` that
+ *                                   python/functions/func.py:40,50 calls)
+ *   Ky = K + |sig2n| I             (python/functions/func.py:183,192)
+ *   L  = cholesky(Ky, lower=True)  (python/functions/func.py:166,184,193 -> LAPACK dpotrf)
+ *   alpha = L^-T L^-1 y            (python/functions/func.py:174-177       -> LAPACK dtrtrs x2)
+ *   nll = y.alpha/2 + sum log L_ii (python/functions/func.py:186,195)
+ *   K* rows . alpha                (sympgpr.f90:62-86,112-124: guessP / calcq / calcP target)
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - fp64, column-major (Fortran order), leading dimensions in elements.
+ *   - `family`: SGPR_FAM_* selects the generated scalar-kernel file of the reference.
+ *   - `hyp` / `nhyp`: the reference's hyper-parameter vector: (lx, ly, sig) for A/B/C
+ *     (sympgpr.f90:17), (lx, ly, p, sig) for D
+ *     (01_pendulum/implicit_period_unknown/func.py:18-19,45-46).  K is scaled by sig.
+ *   - return value: 0 = ok; < 0 = SGPR_E_* (argument / HIP error, text via
+ *     sgpr_last_error()); > 0 = LAPACK-style info "leading minor of order k is not positive
+ *     definite" (the Python layer maps it to numpy.linalg.LinAlgError like SciPy does).
+ *   - `*_host` calls take caller-owned host buffers and stage through HBM; `*_dev` calls
+ *     take device pointers (hipMalloc / torch tensors) and a hipStream_t passed as void*.
+ *   - There is NO CPU fallback: without a usable gfx950 device every compute call
+ *     returns SGPR_E_NODEVICE.
+ */
+#ifndef SYMPGPR_HIP_H
+#define SYMPGPR_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGPR_ABI_VERSION 1
+
+enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
+       SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
+       SGPR_FAM_C = 2,   /* SE x SE                      : 03_henon_heiles/kernels_sq.f90        */
+       SGPR_FAM_D = 3 }; /* periodic, free period p      : 01_pendulum/implicit_period_unknown/kernels.f90 */
+
+/* `which` of sgpr_kernel_eval: the four functions of a kernels*.f90 that enter K */
+enum { SGPR_K_KERN = 0, SGPR_K_DXDX0 = 1, SGPR_K_DYDY0 = 2, SGPR_K_DXDY0 = 3 };
+
+enum { SGPR_E_ARG = -1, SGPR_E_NODEVICE = -2, SGPR_E_HIP = -3, SGPR_E_NOMEM = -4,
+       SGPR_E_STATE = -5 };
+
+/* Gram-build part selection / options (sgpr_gram_pairs_dev `flags`) */
+enum { SGPR_G_QQ = 1, SGPR_G_PQ = 2, SGPR_G_QP = 4, SGPR_G_PP = 8, SGPR_G_ALL = 15,
+       SGPR_G_LOWER = 16,     /* write qq / PP tiles only where they touch row >= col; skip qP */
+       SGPR_G_OCML = 32 };    /* use the ROCm device-libs exp/sincos instead of the in-house ones */
+
+/* fit flags */
+enum { SGPR_FIT_LOWER_ONLY = 1,  /* build only the lower triangle (what the factor reads)   */
+       SGPR_FIT_KEEP_K = 2 };    /* keep an untouched copy of Ky next to L (2x memory)       */
+
+int sgpr_abi_version(void);
+const char *sgpr_last_error(void);
+/* number of usable HIP devices (0 if none); never fails */
+int sgpr_device_count(void);
+/* select the device used by this thread's subsequent calls (default 0) */
+int sgpr_set_device(int dev);
+
+/* ---- stateless host-buffer calls: mirror the f2py object --------------------------------- */
+
+/* sympgpr.build_k(x, y, x0, y0, hyp, K): K is (2n x 2n0), in/out, column-major.
+ * replaces python/05_tokamak/SympGPR/sympgpr.f90:12-38 */
+int sgpr_build_k_host(int family, int n, int n0, const double *x, const double *y,
+                      const double *x0, const double *y0, const double *hyp, int nhyp,
+                      double *K, size_t ldk);
+/* sympgpr.buildkreg(x, y, x0, y0, hyp, K): K is (n x n0).  replaces sympgpr.f90:40-60 */
+int sgpr_buildkreg_host(int family, int n, int n0, const double *x, const double *y,
+                        const double *x0, const double *y0, const double *hyp, int nhyp,
+                        double *K, size_t ldk);
+/* kernels.<name>_num, batched: out[i] = f(xa[i], ya[i], xb[i], yb[i], l...).  `l` holds
+ * (lx, ly) or (lx, ly, p).  replaces the f2py `kernels` module (kernels.f90:1-94) */
+int sgpr_kernel_eval_host(int family, int which, int m, const double *xa, const double *ya,
+                          const double *xb, const double *yb, const double *l, int nl,
+                          double *out);
+/* scipy.linalg.cholesky(A, lower=True) (func.py:166): in place, strict upper zeroed. */
+int sgpr_potrf_host(int n, double *A, size_t lda);
+/* solve_cholesky(L, B) (func.py:174-177): B (n x nrhs) overwritten by L^-T L^-1 B. */
+int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, int nrhs);
+
+/* ---- device-resident fit: the whole nll_chol path without K ever leaving HBM --------------
+ * replaces python/functions/func.py:189-196 (nll_chol) / :165-171 (gpsolve) on (x, x). */
+typedef struct sgpr_fit *sgpr_fit_t;
+
+/* Allocates HBM for an n = 2*n_pts order system and uploads x, y (n_pts each), z (2*n_pts). */
+int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, const double *z,
+                    const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
+                    sgpr_fit_t *out);
+/* new hyper-parameters / targets for the next run (the optimiser loop of the drivers,
+ * 01_pendulum/implicit/main.py:146-151, calls the path ~100x with fixed x) */
+int sgpr_fit_set_hyp(sgpr_fit_t f, const double *hyp, int nhyp, double sig2n);
+int sgpr_fit_set_targets(sgpr_fit_t f, const double *z);
+/* individual stages (asynchronous on the fit's stream) */
+int sgpr_fit_build(sgpr_fit_t f);   /* Ky = build_K(x,x) + |sig2n| I                         */
+int sgpr_fit_factor(sgpr_fit_t f);  /* L in place; returns info > 0 when not PD (this syncs)  */
+int sgpr_fit_solve(sgpr_fit_t f);   /* alpha = L^-T L^-1 z ; nll                              */
+/* all three; returns the factor's info */
+int sgpr_fit_run(sgpr_fit_t f);
+int sgpr_fit_alpha(sgpr_fit_t f, double *alpha_out /* 2*n_pts, host */);
+int sgpr_fit_nll(sgpr_fit_t f, double *nll_out);
+int sgpr_fit_ldiag(sgpr_fit_t f, double *diag_out /* 2*n_pts, host */);
+/* copy the factor (lower, strict upper zeroed) / the matrix as built to a host buffer */
+int sgpr_fit_get_matrix(sgpr_fit_t f, double *A, size_t lda);
+/* extra right-hand sides with the cached factor: B (n x nrhs, host) overwritten */
+int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs);
+/* K*(2 x 2n_pts) rows . alpha for m test points (sympgpr.f90:75-86,112-124 with alpha cached):
+ * out_p[k] = Kstar(1,:).alpha, out_q[k] = Kstar(2,:).alpha */
+int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P, double *out_p,
+                          double *out_q);
+/* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
+int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms);
+/* device pointers of the fit (for callers that own a torch / HIP context): K/L, alpha */
+int sgpr_fit_device_ptrs(sgpr_fit_t f, void **dA, size_t *lda, void **dalpha);
+int sgpr_fit_destroy(sgpr_fit_t f);
+
+/* ---- device-pointer primitives (the tiles a distributed driver composes) ------------------ */
+
+/* Pair-tile Gram build.  For pair rows i = 0..mi-1 (row point b = (xb[i], yb[i])) and pair
+ * columns j = 0..mj-1 (column point a = (xa[j], ya[j])) writes, for each selected part,
+ *   qq[i + j*ld] = sig d2k/dxdx0,  Pq / qP = sig d2k/dxdy0,  PP = sig d2k/dydy0
+ * (the four K(...) assignments of sympgpr.f90:27-34).  `diag_off`: global_row - global_col of
+ * element (0,0); |noise| is added on qq / PP where i + diag_off == j (func.py:192). */
+int sgpr_gram_pairs_dev(int family, int mi, int mj, const double *xb, const double *yb,
+                        const double *xa, const double *ya, const double *hyp, int nhyp,
+                        double *qq, double *Pq, double *qP, double *PP, size_t ld,
+                        long diag_off, double noise, unsigned flags, void *stream);
+/* scalar-kernel Gram tile: G[i + j*ld] = sig k(a_j, b_i)  (sympgpr.f90:54-59) */
+int sgpr_gram_reg_dev(int family, int mi, int mj, const double *xb, const double *yb,
+                      const double *xa, const double *ya, const double *hyp, int nhyp,
+                      double *G, size_t ld, long diag_off, double noise, void *stream);
+
+/* workspace (bytes) sgpr_potrf_dev / sgpr_trsm_rlt_dev need for order n */
+size_t sgpr_potrf_workspace(int n);
+/* lower Cholesky in place; only the lower triangle of A is read or written.
+ * dinfo: device int, 0 or the 1-based failing minor. */
+int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo,
+                   void *stream);
+/* B (m x n) := B L^-T with L (n x n) lower, its diagonal-leaf inverses in `work` as left by
+ * sgpr_potrf_dev on that L (the panel solve of a right-looking step). */
+int sgpr_trsm_rlt_dev(int m, int n, const double *L, size_t ldl, double *B, size_t ldb,
+                      const void *work, void *stream);
+/* C (m x n) := beta C + alpha A (m x k) B(n x k)^T ; lower != 0: only tiles touching
+ * row >= col (+ diag_off) are computed (SYRK-style trailing update). */
+int sgpr_gemm_nt_dev(int m, int n, int k, double alpha, const double *A, size_t lda,
+                     const double *B, size_t ldb, double beta, double *C, size_t ldc, int lower,
+                     long diag_off, void *stream);
+/* alpha-solve on device with the factor and its leaf inverses: b (n) := L^-T L^-1 b */
+int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b,
+                       void *stream);
+
+/* Per-launch HIP-event timing of the MFMA GEMM kernel between begin and end (measurement
+ * aid for bench.py's roofline leg; not part of the reference's interface).
+ * out8: [0..2] launches / algorithmic flop / ms of the 256x128-tile kernel, [3..5] same for the
+ * 128x128-tile kernel, [6..7] flop / ms of the single largest launch. */
+int sgpr_profile_begin(void);
+int sgpr_profile_end(double *out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes binding of libsympgpr_hip.so (include/sympgpr_hip.h).  No compute happens here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+FAMILIES = {"A": 0, "B": 1, "C": 2, "D": 3}
+K_KERN, K_DXDX0, K_DYDY0, K_DXDY0 = 0, 1, 2, 3
+G_QQ, G_PQ, G_QP, G_PP, G_ALL, G_LOWER, G_OCML = 1, 2, 4, 8, 15, 16, 32
+FIT_LOWER_ONLY, FIT_KEEP_K = 1, 2
+E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+class SympGPRError(RuntimeError):
+    pass
+
+
+class NoDeviceError(SympGPRError):
+    pass
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsympgpr_hip.so")
+
+
+# every symbol include/sympgpr_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "sgpr_abi_version": (C.c_int, []),
+    "sgpr_last_error": (C.c_char_p, []),
+    "sgpr_device_count": (C.c_int, []),
+    "sgpr_set_device": (C.c_int, [C.c_int]),
+    "sgpr_build_k_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_size_t]),
+    "sgpr_buildkreg_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_size_t]),
+    "sgpr_kernel_eval_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
+    "sgpr_potrf_host": (C.c_int, [C.c_int, _dp, C.c_size_t]),
+    "sgpr_potrs_host": (C.c_int, [C.c_int, _dp, C.c_size_t, _dp, C.c_size_t, C.c_int]),
+    "sgpr_fit_create": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_uint, _vp,
+                                  C.POINTER(_vp)]),
+    "sgpr_fit_set_hyp": (C.c_int, [_vp, _dp, C.c_int, C.c_double]),
+    "sgpr_fit_set_targets": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_build": (C.c_int, [_vp]),
+    "sgpr_fit_factor": (C.c_int, [_vp]),
+    "sgpr_fit_solve": (C.c_int, [_vp]),
+    "sgpr_fit_run": (C.c_int, [_vp]),
+    "sgpr_fit_alpha": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_nll": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_ldiag": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_get_matrix": (C.c_int, [_vp, _dp, C.c_size_t]),
+    "sgpr_fit_solve_rhs": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
+    "sgpr_fit_predict_rows": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "sgpr_fit_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
+    "sgpr_fit_destroy": (C.c_int, [_vp]),
+    "sgpr_gram_pairs_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp,
+                                      _vp, C.c_size_t, C.c_long, C.c_double, C.c_uint, _vp]),
+    "sgpr_gram_reg_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, C.c_int, _vp, C.c_size_t,
+                                    C.c_long, C.c_double, _vp]),
+    "sgpr_potrf_workspace": (C.c_size_t, [C.c_int]),
+    "sgpr_potrf_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
+    "sgpr_trsm_rlt_dev": (C.c_int, [C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
+    "sgpr_gemm_nt_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t,
+                                   C.c_double, _vp, C.c_size_t, C.c_int, C.c_long, _vp]),
+    "sgpr_profile_begin": (C.c_int, []),
+    "sgpr_profile_end": (C.c_int, [_dp]),
+    "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def load_library():
+    """Load libsympgpr_hip.so and bind every declared symbol.  Raises SympGPRError when the
+    library has not been built -- there is deliberately no fallback implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SympGPRError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or make -C sympgpr_amd/csrc); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgpr_abi_version() != 1:
+        raise SympGPRError("ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def device_count():
+    return load_library().sgpr_device_count()
+
+
+def check(rc, what=""):
+    """0 -> ok; >0 -> LinAlgError like SciPy's cholesky; <0 -> SympGPRError."""
+    if rc == 0:
+        return
+    if rc > 0:
+        raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % rc)
+    msg = load_library().sgpr_last_error().decode(errors="replace")
+    if rc == E_NODEVICE:
+        raise NoDeviceError(msg)
+    raise SympGPRError("%s failed (%d): %s" % (what or "libsympgpr_hip call", rc, msg))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def family_id(fam):
+    if isinstance(fam, str):
+        return FAMILIES[fam]
+    return int(fam)

@@ -1,0 +1,520 @@
+// capi.hip -- extern "C" entry points of libsympgpr_hip.so (see include/sympgpr_hip.h).
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace sgpr {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    g_err = std::string(hipGetErrorString(e)) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? SGPR_E_NOMEM : SGPR_E_HIP;
+}
+
+static int need_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device: libsympgpr_hip.so has no CPU fallback");
+        return SGPR_E_NODEVICE;
+    }
+    return 0;
+}
+
+// small RAII device buffer for the host-pointer calls
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { SGPR_HIP(hipMalloc(&p, bytes ? bytes : 8)); return 0; }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+static int upload(DevBuf &b, const double *h, size_t n, hipStream_t st)
+{
+    int rc = b.alloc(n * sizeof(double));
+    if (rc) return rc;
+    if (n) SGPR_HIP(hipMemcpyAsync(b.p, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+}  // namespace sgpr
+
+using namespace sgpr;
+
+struct sgpr_fit {
+    int family = 0, npts = 0, n = 0;
+    unsigned flags = 0;
+    hipStream_t st = nullptr;
+    KConst kc{};
+    double sig2n = 0.0;
+    double *dx = nullptr, *dy = nullptr, *dz = nullptr, *dA = nullptr, *dalpha = nullptr;
+    double *dscal = nullptr;  // [0] nll, [1] sum log diag
+    int *dinfo = nullptr;
+    void *work = nullptr;
+    size_t lwork = 0;
+    bool built = false, factored = false, solved = false;
+    int info = 0;
+    hipEvent_t ev[6] = {};
+    bool timed[3] = {false, false, false};
+};
+
+extern "C" {
+
+int sgpr_abi_version(void) { return SGPR_ABI_VERSION; }
+const char *sgpr_last_error(void) { return g_err.c_str(); }
+
+int sgpr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int sgpr_set_device(int dev)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    SGPR_HIP(hipSetDevice(dev));
+    return 0;
+}
+
+int sgpr_build_k_host(int family, int n, int n0, const double *x, const double *y, const double *x0,
+                      const double *y0, const double *hyp, int nhyp, double *K, size_t ldk)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || n0 < 0 || ldk < (size_t)(2 * n)) { set_error("build_k: bad shape"); return SGPR_E_ARG; }
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    if (n == 0 || n0 == 0) return 0;
+    DevBuf dx, dy, dx0, dy0, dK;
+    hipStream_t st = nullptr;
+    if ((rc = upload(dx, x, n, st)) || (rc = upload(dy, y, n, st)) || (rc = upload(dx0, x0, n0, st)) ||
+        (rc = upload(dy0, y0, n0, st)))
+        return rc;
+    const size_t ld = 2 * (size_t)n;
+    if ((rc = dK.alloc(ld * 2 * n0 * sizeof(double)))) return rc;
+    double *k = dK.as<double>();
+    rc = gram_pairs(family, n, n0, dx.as<double>(), dy.as<double>(), dx0.as<double>(), dy0.as<double>(),
+                    kc, k, k + n, k + ld * n0, k + n + ld * n0, ld, 0, 0.0, SGPR_G_ALL, st);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(K, ldk * sizeof(double), k, ld * sizeof(double), ld * sizeof(double),
+                              2 * (size_t)n0, hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int sgpr_buildkreg_host(int family, int n, int n0, const double *x, const double *y, const double *x0,
+                        const double *y0, const double *hyp, int nhyp, double *K, size_t ldk)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || n0 < 0 || ldk < (size_t)n) { set_error("buildkreg: bad shape"); return SGPR_E_ARG; }
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    if (n == 0 || n0 == 0) return 0;
+    DevBuf dx, dy, dx0, dy0, dK;
+    hipStream_t st = nullptr;
+    if ((rc = upload(dx, x, n, st)) || (rc = upload(dy, y, n, st)) || (rc = upload(dx0, x0, n0, st)) ||
+        (rc = upload(dy0, y0, n0, st)))
+        return rc;
+    const size_t ld = (size_t)n;
+    if ((rc = dK.alloc(ld * n0 * sizeof(double)))) return rc;
+    rc = gram_reg(family, n, n0, dx.as<double>(), dy.as<double>(), dx0.as<double>(), dy0.as<double>(), kc,
+                  dK.as<double>(), ld, 0, 0.0, st);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(K, ldk * sizeof(double), dK.p, ld * sizeof(double), ld * sizeof(double),
+                              (size_t)n0, hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int sgpr_kernel_eval_host(int family, int which, int m, const double *xa, const double *ya,
+                          const double *xb, const double *yb, const double *l, int nl, double *out)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    KConst kc;
+    if ((rc = make_kconst_l(family, l, nl, &kc))) return rc;
+    if (m <= 0) return 0;
+    DevBuf a, b, c, d, o;
+    hipStream_t st = nullptr;
+    if ((rc = upload(a, xa, m, st)) || (rc = upload(b, ya, m, st)) || (rc = upload(c, xb, m, st)) ||
+        (rc = upload(d, yb, m, st)) || (rc = o.alloc(m * sizeof(double))))
+        return rc;
+    rc = kernel_eval(family, which, m, a.as<double>(), b.as<double>(), c.as<double>(), d.as<double>(), kc,
+                     o.as<double>(), st);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpyAsync(out, o.p, m * sizeof(double), hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+int sgpr_potrf_host(int n, double *A, size_t lda)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && lda < (size_t)n)) { set_error("potrf: bad n / lda"); return SGPR_E_ARG; }
+    if (n == 0) return 0;
+    DevBuf dA, dW, dI;
+    hipStream_t st = nullptr;
+    const size_t ld = (size_t)n;
+    if ((rc = dA.alloc(ld * n * sizeof(double))) || (rc = dW.alloc(potrf_workspace(n))) ||
+        (rc = dI.alloc(sizeof(int))))
+        return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dA.p, ld * sizeof(double), A, lda * sizeof(double), ld * sizeof(double), n,
+                              hipMemcpyHostToDevice, st));
+    if ((rc = potrf(n, dA.as<double>(), ld, dW.p, potrf_workspace(n), dI.as<int>(), st))) return rc;
+    if ((rc = zero_strict_upper(n, dA.as<double>(), ld, st))) return rc;
+    int info = 0;
+    SGPR_HIP(hipMemcpyAsync(&info, dI.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    if (info) return info;
+    SGPR_HIP(hipMemcpy2D(A, lda * sizeof(double), dA.p, ld * sizeof(double), ld * sizeof(double), n,
+                         hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, int nrhs)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || nrhs < 0 || (n > 0 && (ldl < (size_t)n || ldb < (size_t)n))) {
+        set_error("potrs: bad shape");
+        return SGPR_E_ARG;
+    }
+    if (n == 0 || nrhs == 0) return 0;
+    DevBuf dL, dW, dB;
+    hipStream_t st = nullptr;
+    const size_t ld = (size_t)n;
+    if ((rc = dL.alloc(ld * n * sizeof(double))) || (rc = dW.alloc(potrf_workspace(n))) ||
+        (rc = dB.alloc(ld * nrhs * sizeof(double))))
+        return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dL.p, ld * sizeof(double), L, ldl * sizeof(double), ld * sizeof(double), n,
+                              hipMemcpyHostToDevice, st));
+    SGPR_HIP(hipMemcpy2DAsync(dB.p, ld * sizeof(double), B, ldb * sizeof(double), ld * sizeof(double), nrhs,
+                              hipMemcpyHostToDevice, st));
+    if ((rc = leaf_inverses(n, dL.as<double>(), ld, dW.p, nullptr, st))) return rc;
+    for (int r = 0; r < nrhs; ++r)
+        if ((rc = potrs_vec(n, dL.as<double>(), ld, dW.p, dB.as<double>() + (size_t)r * ld, st))) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, ld * sizeof(double), ld * sizeof(double), nrhs,
+                              hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+/* ---- fit handle ---------------------------------------------------------------------------- */
+
+int sgpr_fit_destroy(sgpr_fit_t f)
+{
+    if (!f) return 0;
+    for (void *p : {(void *)f->dx, (void *)f->dy, (void *)f->dz, (void *)f->dA, (void *)f->dalpha,
+                    (void *)f->dscal, (void *)f->dinfo, f->work})
+        if (p) (void)hipFree(p);
+    for (auto &e : f->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete f;
+    return 0;
+}
+
+int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, const double *z,
+                    const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
+                    sgpr_fit_t *out)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (!out || n_pts <= 0 || !x || !y) { set_error("fit_create: bad arguments"); return SGPR_E_ARG; }
+    if (flags & SGPR_FIT_KEEP_K) { set_error("fit_create: SGPR_FIT_KEEP_K not implemented"); return SGPR_E_ARG; }
+    sgpr_fit *f = new (std::nothrow) sgpr_fit;
+    if (!f) return SGPR_E_NOMEM;
+    f->family = family; f->npts = n_pts; f->n = 2 * n_pts; f->flags = flags;
+    f->st = static_cast<hipStream_t>(stream);
+    if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
+    f->sig2n = sig2n;
+    const size_t n = (size_t)f->n;
+    f->lwork = potrf_workspace(f->n);
+    auto fail = [&](int code) { sgpr_fit_destroy(f); return code; };
+#define FIT_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call, __FILE__, __LINE__)); } while (0)
+    FIT_HIP(hipMalloc((void **)&f->dx, n_pts * sizeof(double)));
+    FIT_HIP(hipMalloc((void **)&f->dy, n_pts * sizeof(double)));
+    FIT_HIP(hipMalloc((void **)&f->dz, n * sizeof(double)));
+    FIT_HIP(hipMalloc((void **)&f->dalpha, n * sizeof(double)));
+    FIT_HIP(hipMalloc((void **)&f->dscal, 4 * sizeof(double)));
+    FIT_HIP(hipMalloc((void **)&f->dinfo, sizeof(int)));
+    FIT_HIP(hipMalloc(&f->work, f->lwork));
+    FIT_HIP(hipMalloc((void **)&f->dA, n * n * sizeof(double)));
+    for (auto &e : f->ev) FIT_HIP(hipEventCreate(&e));
+    FIT_HIP(hipMemcpyAsync(f->dx, x, n_pts * sizeof(double), hipMemcpyHostToDevice, f->st));
+    FIT_HIP(hipMemcpyAsync(f->dy, y, n_pts * sizeof(double), hipMemcpyHostToDevice, f->st));
+    if (z) FIT_HIP(hipMemcpyAsync(f->dz, z, n * sizeof(double), hipMemcpyHostToDevice, f->st));
+    else FIT_HIP(hipMemsetAsync(f->dz, 0, n * sizeof(double), f->st));
+    FIT_HIP(hipStreamSynchronize(f->st));
+#undef FIT_HIP
+    *out = f;
+    return 0;
+}
+
+int sgpr_fit_set_hyp(sgpr_fit_t f, const double *hyp, int nhyp, double sig2n)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    int rc = make_kconst(f->family, hyp, nhyp, &f->kc);
+    if (rc) return rc;
+    f->sig2n = sig2n;
+    f->built = f->factored = f->solved = false;
+    return 0;
+}
+
+int sgpr_fit_set_targets(sgpr_fit_t f, const double *z)
+{
+    if (!f || !z) { set_error("null argument"); return SGPR_E_ARG; }
+    SGPR_HIP(hipMemcpyAsync(f->dz, z, (size_t)f->n * sizeof(double), hipMemcpyHostToDevice, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    f->solved = false;
+    return 0;
+}
+
+int sgpr_fit_build(sgpr_fit_t f)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    const size_t n = (size_t)f->n;
+    const int N = f->npts;
+    unsigned flags = SGPR_G_ALL;
+    if (f->flags & SGPR_FIT_LOWER_ONLY) flags |= SGPR_G_LOWER;
+    SGPR_HIP(hipEventRecord(f->ev[0], f->st));
+    // Ky = build_K(x, x) + |sig2n| I  (func.py:191-192), noise fused into the diagonal tiles
+    int rc = gram_pairs(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, f->dA + N,
+                        f->dA + n * N, f->dA + N + n * N, n, 0, std::fabs(f->sig2n), flags, f->st);
+    if (rc) return rc;
+    SGPR_HIP(hipEventRecord(f->ev[1], f->st));
+    f->timed[0] = true;
+    f->built = true;
+    f->factored = f->solved = false;
+    return 0;
+}
+
+int sgpr_fit_factor(sgpr_fit_t f)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    if (!f->built) { set_error("fit_factor: call sgpr_fit_build first"); return SGPR_E_STATE; }
+    SGPR_HIP(hipEventRecord(f->ev[2], f->st));
+    int rc = potrf(f->n, f->dA, (size_t)f->n, f->work, f->lwork, f->dinfo, f->st);
+    if (rc) return rc;
+    SGPR_HIP(hipEventRecord(f->ev[3], f->st));
+    f->timed[1] = true;
+    f->built = false;  // K has been overwritten by L
+    SGPR_HIP(hipMemcpyAsync(&f->info, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    f->factored = f->info == 0;
+    return f->info;
+}
+
+int sgpr_fit_solve(sgpr_fit_t f)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    if (!f->factored) { set_error("fit_solve: no valid factor"); return SGPR_E_STATE; }
+    const size_t n = (size_t)f->n;
+    SGPR_HIP(hipEventRecord(f->ev[4], f->st));
+    SGPR_HIP(hipMemcpyAsync(f->dalpha, f->dz, n * sizeof(double), hipMemcpyDeviceToDevice, f->st));
+    int rc = potrs_vec(f->n, f->dA, n, f->work, f->dalpha, f->st);
+    if (rc) return rc;
+    if ((rc = nll_reduce(f->n, f->dA, n, f->dz, f->dalpha, f->dscal, f->st))) return rc;
+    SGPR_HIP(hipEventRecord(f->ev[5], f->st));
+    f->timed[2] = true;
+    f->solved = true;
+    return 0;
+}
+
+int sgpr_fit_run(sgpr_fit_t f)
+{
+    int rc = sgpr_fit_build(f);
+    if (rc) return rc;
+    if ((rc = sgpr_fit_factor(f))) return rc;
+    return sgpr_fit_solve(f);
+}
+
+int sgpr_fit_alpha(sgpr_fit_t f, double *alpha_out)
+{
+    if (!f || !alpha_out) { set_error("null argument"); return SGPR_E_ARG; }
+    if (!f->solved) { set_error("fit_alpha: not solved"); return SGPR_E_STATE; }
+    SGPR_HIP(hipMemcpyAsync(alpha_out, f->dalpha, (size_t)f->n * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+int sgpr_fit_nll(sgpr_fit_t f, double *nll_out)
+{
+    if (!f || !nll_out) { set_error("null argument"); return SGPR_E_ARG; }
+    if (!f->solved) { set_error("fit_nll: not solved"); return SGPR_E_STATE; }
+    SGPR_HIP(hipMemcpyAsync(nll_out, f->dscal, sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+int sgpr_fit_ldiag(sgpr_fit_t f, double *diag_out)
+{
+    if (!f || !diag_out) { set_error("null argument"); return SGPR_E_ARG; }
+    if (!f->factored) { set_error("fit_ldiag: no valid factor"); return SGPR_E_STATE; }
+    DevBuf d;
+    int rc = d.alloc((size_t)f->n * sizeof(double));
+    if (rc) return rc;
+    if ((rc = copy_diag(f->n, f->dA, (size_t)f->n, d.as<double>(), f->st))) return rc;
+    SGPR_HIP(hipMemcpyAsync(diag_out, d.p, (size_t)f->n * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+int sgpr_fit_get_matrix(sgpr_fit_t f, double *A, size_t lda)
+{
+    if (!f || !A || lda < (size_t)f->n) { set_error("fit_get_matrix: bad arguments"); return SGPR_E_ARG; }
+    if (!f->factored && !f->built) { set_error("fit_get_matrix: nothing built"); return SGPR_E_STATE; }
+    const size_t n = (size_t)f->n;
+    int rc;
+    if (f->factored) {
+        if ((rc = zero_strict_upper(f->n, f->dA, n, f->st))) return rc;
+    } else if (f->flags & SGPR_FIT_LOWER_ONLY) {
+        if ((rc = sym_fill_upper(f->n, f->dA, n, f->st))) return rc;
+    }
+    SGPR_HIP(hipMemcpy2DAsync(A, lda * sizeof(double), f->dA, n * sizeof(double), n * sizeof(double), n,
+                              hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs)
+{
+    if (!f || !B || ldb < (size_t)f->n || nrhs < 0) { set_error("fit_solve_rhs: bad arguments"); return SGPR_E_ARG; }
+    if (!f->factored) { set_error("fit_solve_rhs: no valid factor"); return SGPR_E_STATE; }
+    if (nrhs == 0) return 0;
+    const size_t n = (size_t)f->n;
+    DevBuf dB;
+    int rc = dB.alloc(n * nrhs * sizeof(double));
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dB.p, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs,
+                              hipMemcpyHostToDevice, f->st));
+    for (int r = 0; r < nrhs; ++r)
+        if ((rc = potrs_vec(f->n, f->dA, n, f->work, dB.as<double>() + (size_t)r * n, f->st))) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, n * sizeof(double), n * sizeof(double), nrhs,
+                              hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P, double *out_p,
+                          double *out_q)
+{
+    if (!f || m < 0 || !q || !P || !out_p || !out_q) { set_error("fit_predict_rows: bad arguments"); return SGPR_E_ARG; }
+    if (!f->solved) { set_error("fit_predict_rows: not solved"); return SGPR_E_STATE; }
+    if (m == 0) return 0;
+    DevBuf dq, dP, dop, doq;
+    int rc;
+    if ((rc = upload(dq, q, m, f->st)) || (rc = upload(dP, P, m, f->st)) ||
+        (rc = dop.alloc(m * sizeof(double))) || (rc = doq.alloc(m * sizeof(double))))
+        return rc;
+    rc = predict_rows(f->family, m, dq.as<double>(), dP.as<double>(), f->npts, f->dx, f->dy, f->kc,
+                      f->dalpha, dop.as<double>(), doq.as<double>(), f->st);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpyAsync(out_p, dop.p, m * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipMemcpyAsync(out_q, doq.p, m * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    double *outs[3] = {build_ms, factor_ms, solve_ms};
+    for (int s = 0; s < 3; ++s) {
+        if (!outs[s]) continue;
+        float ms = -1.0f;
+        if (f->timed[s]) SGPR_HIP(hipEventElapsedTime(&ms, f->ev[2 * s], f->ev[2 * s + 1]));
+        *outs[s] = ms;
+    }
+    return 0;
+}
+
+int sgpr_fit_device_ptrs(sgpr_fit_t f, void **dA, size_t *lda, void **dalpha)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    if (dA) *dA = f->dA;
+    if (lda) *lda = (size_t)f->n;
+    if (dalpha) *dalpha = f->dalpha;
+    return 0;
+}
+
+/* ---- device-pointer primitives ---------------------------------------------------------- */
+
+int sgpr_gram_pairs_dev(int family, int mi, int mj, const double *xb, const double *yb,
+                        const double *xa, const double *ya, const double *hyp, int nhyp, double *qq,
+                        double *Pq, double *qP, double *PP, size_t ld, long diag_off, double noise,
+                        unsigned flags, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    return gram_pairs(family, mi, mj, xb, yb, xa, ya, kc, qq, Pq, qP, PP, ld, diag_off, std::fabs(noise),
+                      flags, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_gram_reg_dev(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
+                      const double *ya, const double *hyp, int nhyp, double *G, size_t ld,
+                      long diag_off, double noise, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    return gram_reg(family, mi, mj, xb, yb, xa, ya, kc, G, ld, diag_off, std::fabs(noise),
+                    static_cast<hipStream_t>(stream));
+}
+
+size_t sgpr_potrf_workspace(int n) { return potrf_workspace(n); }
+
+int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return potrf(n, A, lda, work, lwork, dinfo, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_trsm_rlt_dev(int m, int n, const double *L, size_t ldl, double *B, size_t ldb,
+                      const void *work, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return trsm_rlt(m, n, L, ldl, B, ldb, work, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_gemm_nt_dev(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+                     size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,
+                     void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return gemm_nt(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, diag_off,
+                   static_cast<hipStream_t>(stream));
+}
+
+int sgpr_profile_begin(void) { gemm_profile_begin(); return 0; }
+int sgpr_profile_end(double *out8)
+{
+    if (!out8) { set_error("null argument"); return SGPR_E_ARG; }
+    return gemm_profile_end(out8);
+}
+
+int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return potrs_vec(n, L, ldl, work, b, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

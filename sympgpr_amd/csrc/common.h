@@ -1,0 +1,79 @@
+// common.h -- internal declarations shared by the HIP translation units of libsympgpr_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/sympgpr_hip.h"
+
+namespace sgpr {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define SGPR_HIP(call)                                                          \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return ::sgpr::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define SGPR_CHECK_LAUNCH() SGPR_HIP(hipGetLastError())
+
+// Hyper-parameters split the way the reference does (`l = hyp[:-1]; sig = hyp[-1]`),
+// plus the derived constants every Gram kernel uses.
+struct KConst {
+    double lx, ly, p, sig;
+    double lx2, ly2;        // lx^2, ly^2
+    double inv_lx2, inv_ly2;
+    double cxx, cyy, cxy;   // sig*pp/lx^4, sig/ly^4, -sig*pm/(lx^2 ly^2)
+    double hscale;          // 0.5 (family A/B) or p (family D); unused for C
+};
+int make_kconst(int family, const double *hyp, int nhyp, KConst *out);
+int make_kconst_l(int family, const double *l, int nl, KConst *out);  // sig = 1
+
+// ---- gram.hip
+int gram_pairs(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
+               const double *ya, const KConst &kc, double *qq, double *Pq, double *qP, double *PP,
+               size_t ld, long diag_off, double noise, unsigned flags, hipStream_t st);
+int gram_reg(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
+             const double *ya, const KConst &kc, double *G, size_t ld, long diag_off, double noise,
+             hipStream_t st);
+int kernel_eval(int family, int which, int m, const double *xa, const double *ya, const double *xb,
+                const double *yb, const KConst &kc, double *out, hipStream_t st);
+int predict_rows(int family, int m, const double *q, const double *P, int n0, const double *xtr,
+                 const double *ytr, const KConst &kc, const double *alpha, double *out_p,
+                 double *out_q, hipStream_t st);
+int predict_reg(int family, int m, const double *q, const double *P, int n0, const double *xtr,
+                const double *ytr, const KConst &kc, const double *alpha, double *out,
+                hipStream_t st);
+
+// ---- gemm_f64.hip : C = beta C + alpha A B^T on fp64 MFMA tiles
+int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+            size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,
+            hipStream_t st);
+void gemm_profile_begin();
+int gemm_profile_end(double *out8);
+
+// ---- chol.hip : leaf factor / leaf inverse / recursion / solves
+constexpr int LEAF = 128;  // order of the diagonal block factored in LDS by one workgroup
+size_t potrf_workspace(int n);
+int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st);
+int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
+             hipStream_t st);
+int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st);
+int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st);
+
+// ---- blas_small.hip
+int zero_strict_upper(int n, double *A, size_t lda, hipStream_t st);
+int sym_fill_upper(int n, double *A, size_t lda, hipStream_t st);
+int nll_reduce(int n, const double *L, size_t ldl, const double *z, const double *alpha,
+               double *dout /* [0]=0.5 z.alpha + sum log diag */, hipStream_t st);
+int copy_diag(int n, const double *A, size_t lda, double *d, hipStream_t st);
+int transpose(int m, int n, const double *A, size_t lda, double *B, size_t ldb, hipStream_t st);
+int gemv_n_sub(int m, int k, const double *A, size_t lda, const double *x, double *y,
+               hipStream_t st);  // y(m) -= A(m x k) x(k)
+int gemv_t_sub(int m, int k, const double *A, size_t lda, const double *x, double *y,
+               hipStream_t st);  // y(k) -= A(m x k)^T x(m)
+
+}  // namespace sgpr

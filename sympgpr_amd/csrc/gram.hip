@@ -1,0 +1,457 @@
+// gram.hip -- Gram-matrix build for gfx950 (MI355X).
+//
+// Replaces the pair loop of the reference's build_K / buildKreg
+// (python/05_tokamak/SympGPR/sympgpr.f90:25-37, :54-59; pure-Python form
+// python/01_pendulum/implicit/func.py:55-64) and the scalar kernels they call
+// (kernels.f90:1-11,58-94 and the kernels_sq / kernels_sum / period-unknown variants).
+//
+// Roofline: HBM write.  One pair (i,j) yields four fp64 entries = 32 B written and costs one
+// exp + one sincos + ~20 FMA, all on the fp64 VALU.  Layout decisions:
+//   * column-major output, so the row index i is the contiguous one: a thread owns TWO
+//     consecutive rows (one 16-B store per part), a wave writes 1 KiB contiguous per store
+//     instruction, a workgroup owns a 512-row x 32-column pair tile = 4 x 128 KiB of K;
+//   * the 32 column points of the tile are staged once in LDS and read back as broadcasts;
+//   * sig scaling, the |sig2n| diagonal and the lower-triangle cut are fused here (the
+//     reference spends three more n^2 passes on them: sympgpr.f90:37, func.py:192).
+#include "common.h"
+#include "devmath.h"
+
+namespace sgpr {
+
+namespace {
+
+constexpr int GT = 256;        // threads per workgroup
+constexpr int TI = 2 * GT;     // pair rows per tile (2 per thread)
+constexpr int TJ = 32;         // pair columns per tile
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+struct GramArgs {
+    int mi, mj;
+    const double *xb, *yb, *xa, *ya;
+    double *dst[4];  // qq, Pq, qP, PP
+    size_t ld;
+    long diag_off;
+    double noise;
+    unsigned flags;
+    KConst kc;
+};
+
+// One pair: a = column ("0") point, b = row point -- the argument order build_K uses
+// (sympgpr.f90:27-34: f(x0(j), y0(j), x(i), y(i), ...)).
+template <int FAM, bool OCML>
+__device__ __forceinline__ void pair_eval(double xa, double ya, double xb, double yb,
+                                          const KConst &kc, double &kxx, double &kxy, double &kyy)
+{
+    const double dy = ya - yb;
+    const double dy2 = dy * dy;
+    if constexpr (FAM == SGPR_FAM_C) {
+        // kernels_sq.f90:55-87
+        const double dx = xa - xb;
+        const double dx2 = dx * dx;
+        const double E = exp_sel<OCML>(-0.5 * (dy2 * kc.inv_ly2) - 0.5 * (dx2 * kc.inv_lx2));
+        kxx = kc.cxx * (kc.lx2 - dx2) * E;
+        kyy = kc.cyy * (kc.ly2 - dy2) * E;
+        kxy = kc.cxy * (dx * dy) * E;
+    } else {
+        // A: h = 0.5 x_a - 0.5 x_b (kernels.f90:66-69); D: h = p (x_a - x_b)
+        // (implicit_period_unknown/kernels.f90:72-74).  Scaling by 0.5 is exact, so the two
+        // forms round identically for A.
+        const double h = kc.hscale * (xa - xb);
+        double s, c;
+        sincos_sel<OCML>(h, s, c);
+        const double s2 = s * s;
+        const double sc = s * c;
+        const double cos2h = __builtin_fma(-2.0, s2, 1.0);  // cos(x_a - x_b) resp. cos(2p dx)
+        if constexpr (FAM == SGPR_FAM_B) {
+            // kernels_sum.f90:58-88: the q and P factors separate, mixed block is zero.
+            const double Ex = exp_sel<OCML>(-0.5 * (s2 * kc.inv_lx2));
+            // the reference writes the P exponent expanded (kernels_sum.f90:9,76); keep its
+            // operation order (no contraction) so the cancellation error is the same one.
+            const double t = __dadd_rn(__dadd_rn(__dmul_rn(-0.5, __dmul_rn(ya, ya)),
+                                                 __dmul_rn(1.0, __dmul_rn(ya, yb))),
+                                       -__dmul_rn(0.5, __dmul_rn(yb, yb)));
+            const double Ey = exp_sel<OCML>(t * kc.inv_ly2);
+            kxx = kc.cxx * (kc.lx2 * cos2h - sc * sc) * Ex;
+            kyy = kc.cyy * (kc.ly2 - dy2) * Ey;
+            kxy = 0.0;
+        } else {
+            const double E = exp_sel<OCML>(-0.5 * (dy2 * kc.inv_ly2) - 0.5 * (s2 * kc.inv_lx2));
+            kxx = kc.cxx * (kc.lx2 * cos2h - sc * sc) * E;
+            kyy = kc.cyy * (kc.ly2 - dy2) * E;
+            kxy = kc.cxy * (dy * sc) * E;
+        }
+    }
+}
+
+// scalar kernel k(a, b) (kern_num): kernels.f90:1-11 and variants
+template <int FAM, bool OCML>
+__device__ __forceinline__ double kern_eval(double xa, double ya, double xb, double yb,
+                                            const KConst &kc)
+{
+    const double dy = ya - yb;
+    if constexpr (FAM == SGPR_FAM_C) {
+        const double dx = xa - xb;
+        return exp_sel<OCML>(-0.5 * (dy * dy * kc.inv_ly2) - 0.5 * (dx * dx * kc.inv_lx2));
+    } else {
+        const double h = kc.hscale * (xa - xb);
+        double s, c;
+        sincos_sel<OCML>(h, s, c);
+        if constexpr (FAM == SGPR_FAM_B) {
+            const double t = __dadd_rn(__dadd_rn(__dmul_rn(-0.5, __dmul_rn(ya, ya)),
+                                                 __dmul_rn(1.0, __dmul_rn(ya, yb))),
+                                       -__dmul_rn(0.5, __dmul_rn(yb, yb)));
+            return exp_sel<OCML>(t * kc.inv_ly2) + exp_sel<OCML>(-0.5 * (s * s * kc.inv_lx2));
+        } else {
+            return exp_sel<OCML>(-0.5 * (dy * dy * kc.inv_ly2) - 0.5 * (s * s * kc.inv_lx2));
+        }
+    }
+}
+
+template <int FAM, bool OCML>
+__global__ __launch_bounds__(GT) void gram_pairs_kernel(const GramArgs a)
+{
+    __shared__ double sxa[TJ], sya[TJ];
+    const int i0 = blockIdx.x * TI;
+    const int j0 = blockIdx.y * TJ;
+    const int t = threadIdx.x;
+    const int nj = min(TJ, a.mj - j0);
+    if (t < nj) {
+        sxa[t] = a.xa[j0 + t];
+        sya[t] = a.ya[j0 + t];
+    }
+    // which parts does this tile write?  (block-uniform)
+    const bool lower = a.flags & SGPR_G_LOWER;
+    const long last_row = (long)min(i0 + TI, a.mi) - 1 + a.diag_off;
+    const bool on_or_below = !lower || last_row >= (long)j0;
+    double *const pqq = (a.flags & SGPR_G_QQ) && on_or_below ? a.dst[0] : nullptr;
+    double *const pPq = (a.flags & SGPR_G_PQ) ? a.dst[1] : nullptr;
+    double *const pqP = (a.flags & SGPR_G_QP) && !lower ? a.dst[2] : nullptr;
+    double *const pPP = (a.flags & SGPR_G_PP) && on_or_below ? a.dst[3] : nullptr;
+    __syncthreads();
+    if (!pqq && !pPq && !pqP && !pPP) return;
+
+    const int i = i0 + 2 * t;
+    const bool v0 = i < a.mi, v1 = i + 1 < a.mi;
+    const double xb0 = v0 ? a.xb[i] : 0.0, yb0 = v0 ? a.yb[i] : 0.0;
+    const double xb1 = v1 ? a.xb[i + 1] : 0.0, yb1 = v1 ? a.yb[i + 1] : 0.0;
+    // 16-B vector stores need every part's (i, j) address 16-B aligned: i is even, so the
+    // base pointers and ld decide (block-uniform); the ragged last row tile goes scalar.
+    const bool vec = (i0 + TI <= a.mi) && ((a.ld & 1) == 0) &&
+                     ((((uintptr_t)a.dst[0] | (uintptr_t)a.dst[1] | (uintptr_t)a.dst[2] |
+                        (uintptr_t)a.dst[3]) & 15) == 0);
+    const long d0 = (long)i + a.diag_off;  // global column that is "diagonal" for row i
+    const double noise = a.noise;
+
+    if (vec) {
+#pragma unroll 2
+        for (int jj = 0; jj < nj; ++jj) {
+            const double xa = sxa[jj], ya = sya[jj];
+            double kxx0, kxy0, kyy0, kxx1, kxy1, kyy1;
+            pair_eval<FAM, OCML>(xa, ya, xb0, yb0, a.kc, kxx0, kxy0, kyy0);
+            pair_eval<FAM, OCML>(xa, ya, xb1, yb1, a.kc, kxx1, kxy1, kyy1);
+            const long j = j0 + jj;
+            const double n0 = (d0 == j) ? noise : 0.0, n1 = (d0 + 1 == j) ? noise : 0.0;
+            const size_t off = (size_t)i + (size_t)j * a.ld;
+            if (pqq) *reinterpret_cast<double2_t *>(pqq + off) = double2_t{kxx0 + n0, kxx1 + n1};
+            if (pPq) *reinterpret_cast<double2_t *>(pPq + off) = double2_t{kxy0, kxy1};
+            if (pqP) *reinterpret_cast<double2_t *>(pqP + off) = double2_t{kxy0, kxy1};
+            if (pPP) *reinterpret_cast<double2_t *>(pPP + off) = double2_t{kyy0 + n0, kyy1 + n1};
+        }
+    } else {
+        for (int jj = 0; jj < nj; ++jj) {
+            const double xa = sxa[jj], ya = sya[jj];
+            double kxx0, kxy0, kyy0, kxx1, kxy1, kyy1;
+            pair_eval<FAM, OCML>(xa, ya, xb0, yb0, a.kc, kxx0, kxy0, kyy0);
+            pair_eval<FAM, OCML>(xa, ya, xb1, yb1, a.kc, kxx1, kxy1, kyy1);
+            const long j = j0 + jj;
+            const double n0 = (d0 == j) ? noise : 0.0, n1 = (d0 + 1 == j) ? noise : 0.0;
+            const size_t off = (size_t)i + (size_t)j * a.ld;
+            if (v0) {
+                if (pqq) pqq[off] = kxx0 + n0;
+                if (pPq) pPq[off] = kxy0;
+                if (pqP) pqP[off] = kxy0;
+                if (pPP) pPP[off] = kyy0 + n0;
+            }
+            if (v1) {
+                if (pqq) pqq[off + 1] = kxx1 + n1;
+                if (pPq) pPq[off + 1] = kxy1;
+                if (pqP) pqP[off + 1] = kxy1;
+                if (pPP) pPP[off + 1] = kyy1 + n1;
+            }
+        }
+    }
+}
+
+struct RegArgs {
+    int mi, mj;
+    const double *xb, *yb, *xa, *ya;
+    double *G;
+    size_t ld;
+    long diag_off;
+    double noise;
+    KConst kc;
+};
+
+template <int FAM, bool OCML>
+__global__ __launch_bounds__(GT) void gram_reg_kernel(const RegArgs a)
+{
+    __shared__ double sxa[TJ], sya[TJ];
+    const int i0 = blockIdx.x * TI;
+    const int j0 = blockIdx.y * TJ;
+    const int t = threadIdx.x;
+    const int nj = min(TJ, a.mj - j0);
+    if (t < nj) {
+        sxa[t] = a.xa[j0 + t];
+        sya[t] = a.ya[j0 + t];
+    }
+    __syncthreads();
+    const int i = i0 + 2 * t;
+    const bool v0 = i < a.mi, v1 = i + 1 < a.mi;
+    const double xb0 = v0 ? a.xb[i] : 0.0, yb0 = v0 ? a.yb[i] : 0.0;
+    const double xb1 = v1 ? a.xb[i + 1] : 0.0, yb1 = v1 ? a.yb[i + 1] : 0.0;
+    const bool vec = (i0 + TI <= a.mi) && ((a.ld & 1) == 0) && (((uintptr_t)a.G & 15) == 0);
+    const long d0 = (long)i + a.diag_off;
+    for (int jj = 0; jj < nj; ++jj) {
+        const double xa = sxa[jj], ya = sya[jj];
+        const long j = j0 + jj;
+        const double k0 = a.kc.sig * kern_eval<FAM, OCML>(xa, ya, xb0, yb0, a.kc) +
+                          ((d0 == j) ? a.noise : 0.0);
+        const double k1 = a.kc.sig * kern_eval<FAM, OCML>(xa, ya, xb1, yb1, a.kc) +
+                          ((d0 + 1 == j) ? a.noise : 0.0);
+        const size_t off = (size_t)i + (size_t)j * a.ld;
+        if (vec) {
+            *reinterpret_cast<double2_t *>(a.G + off) = double2_t{k0, k1};
+        } else {
+            if (v0) a.G[off] = k0;
+            if (v1) a.G[off + 1] = k1;
+        }
+    }
+}
+
+// kernels.<name>_num, elementwise (sig = 1)
+template <int FAM>
+__global__ void kernel_eval_kernel(int which, int m, const double *xa, const double *ya,
+                                   const double *xb, const double *yb, const KConst kc, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double r;
+    if (which == SGPR_K_KERN) {
+        r = kern_eval<FAM, false>(xa[i], ya[i], xb[i], yb[i], kc);
+    } else {
+        double kxx, kxy, kyy;
+        pair_eval<FAM, false>(xa[i], ya[i], xb[i], yb[i], kc, kxx, kxy, kyy);
+        r = which == SGPR_K_DXDX0 ? kxx : (which == SGPR_K_DYDY0 ? kyy : kxy);
+    }
+    out[i] = r;
+}
+
+// K*(2 x 2n0) . alpha for one test point per workgroup (sympgpr.f90:75-86, :112-124 with
+// alpha = Kyinv ztrain cached): row 1 -> out_p, row 2 -> out_q.
+template <int FAM>
+__global__ __launch_bounds__(GT) void predict_rows_kernel(int n0, const double *q, const double *P,
+                                                          const double *xtr, const double *ytr,
+                                                          const KConst kc, const double *alpha,
+                                                          double *out_p, double *out_q)
+{
+    const int k = blockIdx.x;
+    const double xb = q[k], yb = P[k];
+    double r1 = 0.0, r2 = 0.0;
+    for (int j = threadIdx.x; j < n0; j += GT) {
+        double kxx, kxy, kyy;
+        pair_eval<FAM, false>(xtr[j], ytr[j], xb, yb, kc, kxx, kxy, kyy);
+        const double a1 = alpha[j], a2 = alpha[n0 + j];
+        r1 += kxx * a1 + kxy * a2;
+        r2 += kxy * a1 + kyy * a2;
+    }
+    __shared__ double s1[GT / 64], s2[GT / 64];
+    for (int o = 32; o > 0; o >>= 1) {
+        r1 += __shfl_down(r1, o, 64);
+        r2 += __shfl_down(r2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s1[threadIdx.x >> 6] = r1;
+        s2[threadIdx.x >> 6] = r2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < GT / 64; ++w) {
+            t1 += s1[w];
+            t2 += s2[w];
+        }
+        out_p[k] = t1;
+        out_q[k] = t2;
+    }
+}
+
+// Kstar(1 x n0) . alpha_p with the scalar kernel (sympgpr.f90:62-73 guessP)
+template <int FAM>
+__global__ __launch_bounds__(GT) void predict_reg_kernel(int n0, const double *q, const double *P,
+                                                         const double *xtr, const double *ytr,
+                                                         const KConst kc, const double *alpha,
+                                                         double *out)
+{
+    const int k = blockIdx.x;
+    const double xb = q[k], yb = P[k];
+    double r = 0.0;
+    for (int j = threadIdx.x; j < n0; j += GT)
+        r += kc.sig * kern_eval<FAM, false>(xtr[j], ytr[j], xb, yb, kc) * alpha[j];
+    __shared__ double s1[GT / 64];
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o, 64);
+    if ((threadIdx.x & 63) == 0) s1[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < GT / 64; ++w) t += s1[w];
+        out[k] = t;
+    }
+}
+
+template <typename F>
+int dispatch_family(int family, F &&f)
+{
+    switch (family) {
+    case SGPR_FAM_A: return f(std::integral_constant<int, SGPR_FAM_A>());
+    case SGPR_FAM_B: return f(std::integral_constant<int, SGPR_FAM_B>());
+    case SGPR_FAM_C: return f(std::integral_constant<int, SGPR_FAM_C>());
+    case SGPR_FAM_D: return f(std::integral_constant<int, SGPR_FAM_D>());
+    }
+    set_error("unknown kernel family");
+    return SGPR_E_ARG;
+}
+
+}  // namespace
+
+int make_kconst(int family, const double *hyp, int nhyp, KConst *out)
+{
+    const int need = family == SGPR_FAM_D ? 4 : 3;
+    if (family < 0 || family > 3 || !hyp || nhyp != need) {
+        set_error("hyp must hold (lx, ly, sig) -- (lx, ly, p, sig) for family D");
+        return SGPR_E_ARG;
+    }
+    KConst k{};
+    k.lx = hyp[0];
+    k.ly = hyp[1];
+    k.p = family == SGPR_FAM_D ? hyp[2] : 0.0;
+    k.sig = hyp[nhyp - 1];
+    k.lx2 = k.lx * k.lx;
+    k.ly2 = k.ly * k.ly;
+    k.inv_lx2 = 1.0 / k.lx2;
+    k.inv_ly2 = 1.0 / k.ly2;
+    const double pp = family == SGPR_FAM_D ? k.p * k.p : (family == SGPR_FAM_C ? 1.0 : 0.25);
+    const double pm = family == SGPR_FAM_D ? k.p : (family == SGPR_FAM_C ? 1.0 : 0.5);
+    k.cxx = k.sig * pp / (k.lx2 * k.lx2);
+    k.cyy = k.sig / (k.ly2 * k.ly2);
+    k.cxy = -k.sig * pm / (k.lx2 * k.ly2);
+    k.hscale = family == SGPR_FAM_D ? k.p : 0.5;
+    *out = k;
+    return 0;
+}
+
+int make_kconst_l(int family, const double *l, int nl, KConst *out)
+{
+    double h[4];
+    const int need = family == SGPR_FAM_D ? 3 : 2;
+    if (!l || nl != need) {
+        set_error("l must hold (lx, ly) -- (lx, ly, p) for family D");
+        return SGPR_E_ARG;
+    }
+    for (int i = 0; i < nl; ++i) h[i] = l[i];
+    h[nl] = 1.0;
+    return make_kconst(family, h, nl + 1, out);
+}
+
+int gram_pairs(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
+               const double *ya, const KConst &kc, double *qq, double *Pq, double *qP, double *PP,
+               size_t ld, long diag_off, double noise, unsigned flags, hipStream_t st)
+{
+    if (mi < 0 || mj < 0) { set_error("negative extent"); return SGPR_E_ARG; }
+    if (mi == 0 || mj == 0) return 0;
+    unsigned parts = flags & SGPR_G_ALL;
+    if (!qq) parts &= ~SGPR_G_QQ;
+    if (!Pq) parts &= ~SGPR_G_PQ;
+    if (!qP) parts &= ~SGPR_G_QP;
+    if (!PP) parts &= ~SGPR_G_PP;
+    if (!parts) return 0;
+    if (ld < (size_t)mi) { set_error("ld smaller than the tile's row count"); return SGPR_E_ARG; }
+    GramArgs a;
+    a.mi = mi; a.mj = mj; a.xb = xb; a.yb = yb; a.xa = xa; a.ya = ya;
+    a.dst[0] = qq; a.dst[1] = Pq; a.dst[2] = qP; a.dst[3] = PP;
+    a.ld = ld; a.diag_off = diag_off; a.noise = noise;
+    a.flags = parts | (flags & SGPR_G_LOWER);
+    a.kc = kc;
+    const dim3 grid((mi + TI - 1) / TI, (mj + TJ - 1) / TJ);
+    if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
+    const bool ocml = flags & SGPR_G_OCML;
+    return dispatch_family(family, [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        if (ocml) hipLaunchKernelGGL((gram_pairs_kernel<F, true>), grid, dim3(GT), 0, st, a);
+        else      hipLaunchKernelGGL((gram_pairs_kernel<F, false>), grid, dim3(GT), 0, st, a);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+int gram_reg(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
+             const double *ya, const KConst &kc, double *G, size_t ld, long diag_off, double noise,
+             hipStream_t st)
+{
+    if (mi < 0 || mj < 0) { set_error("negative extent"); return SGPR_E_ARG; }
+    if (mi == 0 || mj == 0) return 0;
+    if (ld < (size_t)mi) { set_error("ld smaller than the tile's row count"); return SGPR_E_ARG; }
+    RegArgs a{mi, mj, xb, yb, xa, ya, G, ld, diag_off, noise, kc};
+    const dim3 grid((mi + TI - 1) / TI, (mj + TJ - 1) / TJ);
+    if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
+    return dispatch_family(family, [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        hipLaunchKernelGGL((gram_reg_kernel<F, false>), grid, dim3(GT), 0, st, a);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+int kernel_eval(int family, int which, int m, const double *xa, const double *ya, const double *xb,
+                const double *yb, const KConst &kc, double *out, hipStream_t st)
+{
+    if (m <= 0) return 0;
+    if (which < 0 || which > 3) { set_error("unknown kernel function"); return SGPR_E_ARG; }
+    return dispatch_family(family, [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        hipLaunchKernelGGL((kernel_eval_kernel<F>), dim3((m + 255) / 256), dim3(256), 0, st, which,
+                           m, xa, ya, xb, yb, kc, out);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+int predict_rows(int family, int m, const double *q, const double *P, int n0, const double *xtr,
+                 const double *ytr, const KConst &kc, const double *alpha, double *out_p,
+                 double *out_q, hipStream_t st)
+{
+    if (m <= 0) return 0;
+    return dispatch_family(family, [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        hipLaunchKernelGGL((predict_rows_kernel<F>), dim3(m), dim3(GT), 0, st, n0, q, P, xtr, ytr,
+                           kc, alpha, out_p, out_q);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+int predict_reg(int family, int m, const double *q, const double *P, int n0, const double *xtr,
+                const double *ytr, const KConst &kc, const double *alpha, double *out,
+                hipStream_t st)
+{
+    if (m <= 0) return 0;
+    return dispatch_family(family, [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        hipLaunchKernelGGL((predict_reg_kernel<F>), dim3(m), dim3(GT), 0, st, n0, q, P, xtr, ytr,
+                           kc, alpha, out);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+}  // namespace sgpr

@@ -1,0 +1,112 @@
+"""Device-resident fit: Gram build + Cholesky + alpha without K ever leaving HBM.
+
+Host-side owner of a ``sgpr_fit_t`` handle (include/sympgpr_hip.h); the same sequence the
+reference runs in ``nll_chol`` / ``gpsolve`` (python/functions/func.py:165-171,189-196).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class SympFit:
+    def __init__(self, family, x, y, z, hyp, sig2n, lower_only=True, stream=None):
+        self._lib = L.load_library()
+        self._h = C.c_void_p()
+        x, y, hyp = L.f64(x), L.f64(y), L.f64(hyp)
+        if x.shape != y.shape or x.ndim != 1:
+            raise ValueError("x and y must be 1-D arrays of equal length")
+        self.n_pts = len(x)
+        self.n = 2 * self.n_pts
+        z = L.f64(z) if z is not None else np.zeros(self.n)
+        if z.shape != (self.n,):
+            raise ValueError("z must have length 2*len(x)")
+        flags = L.FIT_LOWER_ONLY if lower_only else 0
+        L.check(self._lib.sgpr_fit_create(L.family_id(family), self.n_pts, L.dptr(x), L.dptr(y), L.dptr(z),
+                                          L.dptr(hyp), len(hyp), float(sig2n), flags,
+                                          C.c_void_p(stream or 0), C.byref(self._h)), "sgpr_fit_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.sgpr_fit_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_hyp(self, hyp, sig2n):
+        hyp = L.f64(hyp)
+        L.check(self._lib.sgpr_fit_set_hyp(self._h, L.dptr(hyp), len(hyp), float(sig2n)), "sgpr_fit_set_hyp")
+
+    def set_targets(self, z):
+        z = L.f64(z)
+        if z.shape != (self.n,):
+            raise ValueError("z must have length 2*n_pts")
+        L.check(self._lib.sgpr_fit_set_targets(self._h, L.dptr(z)), "sgpr_fit_set_targets")
+
+    def build(self):
+        L.check(self._lib.sgpr_fit_build(self._h), "sgpr_fit_build")
+
+    def factor(self):
+        L.check(self._lib.sgpr_fit_factor(self._h), "sgpr_fit_factor")
+
+    def solve(self):
+        L.check(self._lib.sgpr_fit_solve(self._h), "sgpr_fit_solve")
+
+    def run(self):
+        L.check(self._lib.sgpr_fit_run(self._h), "sgpr_fit_run")
+        return self
+
+    def alpha(self):
+        out = np.empty(self.n)
+        L.check(self._lib.sgpr_fit_alpha(self._h, L.dptr(out)), "sgpr_fit_alpha")
+        return out
+
+    def nll(self):
+        v = C.c_double()
+        L.check(self._lib.sgpr_fit_nll(self._h, C.cast(C.byref(v), L._dp)), "sgpr_fit_nll")
+        return v.value
+
+    def ldiag(self):
+        out = np.empty(self.n)
+        L.check(self._lib.sgpr_fit_ldiag(self._h, L.dptr(out)), "sgpr_fit_ldiag")
+        return out
+
+    def matrix(self):
+        """The factor L (after factor()) or Ky (after build()), as an F-ordered host array."""
+        A = np.empty((self.n, self.n), order="F")
+        L.check(self._lib.sgpr_fit_get_matrix(self._h, L.dptr(A), self.n), "sgpr_fit_get_matrix")
+        return A
+
+    def solve_rhs(self, B):
+        B = np.array(B, dtype=np.float64, order="F")
+        nrhs = 1 if B.ndim == 1 else B.shape[1]
+        if B.shape[0] != self.n:
+            raise ValueError("B must have 2*n_pts rows")
+        L.check(self._lib.sgpr_fit_solve_rhs(self._h, L.dptr(B), self.n, nrhs), "sgpr_fit_solve_rhs")
+        return B
+
+    def predict_rows(self, q, P):
+        q, P = L.f64(np.atleast_1d(q)), L.f64(np.atleast_1d(P))
+        m = len(q)
+        op, oq = np.empty(m), np.empty(m)
+        L.check(self._lib.sgpr_fit_predict_rows(self._h, m, L.dptr(q), L.dptr(P), L.dptr(op), L.dptr(oq)),
+                "sgpr_fit_predict_rows")
+        return op, oq
+
+    def stage_ms(self):
+        b, f, s = C.c_double(), C.c_double(), C.c_double()
+        c = lambda v: C.cast(C.byref(v), L._dp)
+        L.check(self._lib.sgpr_fit_stage_ms(self._h, c(b), c(f), c(s)), "sgpr_fit_stage_ms")
+        return b.value, f.value, s.value
+
+    def device_ptrs(self):
+        dA, lda, dal = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        L.check(self._lib.sgpr_fit_device_ptrs(self._h, C.byref(dA), C.byref(lda), C.byref(dal)))
+        return dA.value, lda.value, dal.value

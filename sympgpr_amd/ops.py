@@ -1,0 +1,100 @@
+"""Host-array front-ends of the C ABI (NumPy in, NumPy out).  Each call stages through HBM;
+large problems should use ``fit.SympFit`` which keeps K on the device."""
+import numpy as np
+
+from . import _lib as L
+
+_FAMILY = "A"
+
+
+def set_family(fam):
+    """Select which generated kernels file of the reference is mirrored (default "A":
+    periodic x SE, python/05_tokamak/SympGPR/kernels.f90).  The reference selects it by
+    which kernels*.f90 was compiled into the `kernels` / `sympgpr` module."""
+    global _FAMILY
+    if fam not in L.FAMILIES:
+        raise ValueError("family must be one of %s" % sorted(L.FAMILIES))
+    _FAMILY = fam
+
+
+def get_family():
+    return _FAMILY
+
+
+def _check_inout(K, shape):
+    # f2py semantics for intent(inout) (sympgpr.f90:18): float64, F-contiguous, exact shape
+    if not isinstance(K, np.ndarray) or K.dtype != np.float64:
+        raise ValueError("K must be a float64 numpy array (intent(inout))")
+    if K.shape != shape:
+        raise ValueError("K has shape %s, expected %s" % (K.shape, shape))
+    if not (K.flags.f_contiguous and K.flags.writeable):
+        raise ValueError("failed to initialize intent(inout) array -- input not fortran contiguous")
+
+
+def build_k(x, y, x0, y0, hyp, K, family=None):
+    """sympgpr.build_k(x, y, x0, y0, hyp, K): fills K (2N x 2N0) in place
+    (python/05_tokamak/SympGPR/sympgpr.f90:12-38)."""
+    lib = L.load_library()
+    x, y, x0, y0, hyp = map(L.f64, (np.atleast_1d(x), np.atleast_1d(y), np.atleast_1d(x0), np.atleast_1d(y0), hyp))
+    n, n0 = K.shape[0] // 2, K.shape[1] // 2
+    _check_inout(K, (2 * n, 2 * n0))
+    if len(x) < n or len(y) < n or len(x0) < n0 or len(y0) < n0:
+        raise ValueError("coordinate arrays shorter than K's block size")
+    L.check(lib.sgpr_build_k_host(L.family_id(family or _FAMILY), n, n0, L.dptr(x), L.dptr(y), L.dptr(x0),
+                                  L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(K), max(K.shape[0], 1)),
+            "sgpr_build_k_host")
+
+
+def buildkreg(x, y, x0, y0, hyp, K, family=None):
+    """sympgpr.buildkreg(x, y, x0, y0, hyp, K): fills K (N x N0) in place (sympgpr.f90:40-60)."""
+    lib = L.load_library()
+    x, y, x0, y0, hyp = map(L.f64, (np.atleast_1d(x), np.atleast_1d(y), np.atleast_1d(x0), np.atleast_1d(y0), hyp))
+    n, n0 = K.shape
+    _check_inout(K, (n, n0))
+    if len(x) < n or len(y) < n or len(x0) < n0 or len(y0) < n0:
+        raise ValueError("coordinate arrays shorter than K's shape")
+    L.check(lib.sgpr_buildkreg_host(L.family_id(family or _FAMILY), n, n0, L.dptr(x), L.dptr(y), L.dptr(x0),
+                                    L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(K), max(n, 1)),
+            "sgpr_buildkreg_host")
+
+
+def kernel_eval(which, x_a, y_a, x_b, y_b, l, family=None):
+    """kernels.<name>_num(x_a, y_a, x_b, y_b, lx, ly[, p]) -- scalar or elementwise arrays."""
+    lib = L.load_library()
+    scalar = np.ndim(x_a) == 0 and np.ndim(y_a) == 0 and np.ndim(x_b) == 0 and np.ndim(y_b) == 0
+    xa, ya, xb, yb = np.broadcast_arrays(*[np.asarray(v, dtype=np.float64) for v in (x_a, y_a, x_b, y_b)])
+    shape = xa.shape
+    xa, ya, xb, yb = (np.ascontiguousarray(v).ravel() for v in (xa, ya, xb, yb))
+    l = L.f64(l)
+    out = np.empty(len(xa))
+    L.check(lib.sgpr_kernel_eval_host(L.family_id(family or _FAMILY), which, len(xa), L.dptr(xa), L.dptr(ya),
+                                      L.dptr(xb), L.dptr(yb), L.dptr(l), len(l), L.dptr(out)),
+            "sgpr_kernel_eval_host")
+    return float(out[0]) if scalar else out.reshape(shape)
+
+
+def cholesky(Ky, lower=True):
+    """scipy.linalg.cholesky(Ky, lower=True) (python/functions/func.py:166,184,193):
+    returns a new F-ordered L with a clean upper triangle; LinAlgError when not PD."""
+    if not lower:
+        raise ValueError("only lower=True is used by the reference and implemented")
+    lib = L.load_library()
+    A = np.array(Ky, dtype=np.float64, order="F")
+    if A.ndim != 2 or A.shape[0] != A.shape[1]:
+        raise ValueError("expected square matrix")
+    L.check(lib.sgpr_potrf_host(A.shape[0], L.dptr(A), max(A.shape[0], 1)), "sgpr_potrf_host")
+    return A
+
+
+def solve_cholesky(Lfac, b):
+    """solve_triangular(L.T, solve_triangular(L, b, lower=True), lower=False)
+    (python/functions/func.py:174-177)."""
+    lib = L.load_library()
+    Lf = np.asfortranarray(Lfac, dtype=np.float64)
+    B = np.array(b, dtype=np.float64, order="F")
+    n = Lf.shape[0]
+    if B.shape[0] != n:
+        raise ValueError("shapes of L and b are incompatible")
+    nrhs = 1 if B.ndim == 1 else B.shape[1]
+    L.check(lib.sgpr_potrs_host(n, L.dptr(Lf), max(n, 1), L.dptr(B), max(n, 1), nrhs), "sgpr_potrs_host")
+    return B
