@@ -78,6 +78,15 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 /
+    # libhsa-runtime64.  Loaded after /opt/rocm's copy they become a SECOND runtime that finds
+    # no GPU ("No HIP GPUs are available"); loaded first, our NEEDED libamdhip64.so.7 resolves
+    # to the copy already in the process.  So when torch is installed, it goes first.
+    if os.environ.get("SYMPGPR_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise SympGPRError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(or make -C sympgpr_amd/csrc); there is no CPU fallback" % path)
