@@ -161,6 +161,18 @@ int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, dou
 int sgpr_profile_begin(void);
 int sgpr_profile_end(double *out8);
 
+/* Roofline calibration probes (measurement aids): a register-only fp64 MFMA issue loop with
+ * `waves_per_simd` waves on every SIMD, and a streaming 16-B/lane write of `bytes` bytes. */
+int sgpr_probe_mfma_f64(int waves_per_simd, int iters, double *tflops);
+int sgpr_probe_hbm_write(size_t bytes, int reps, double *gbs);
+/* out3: TFLOP/s, shader cycles per MFMA per SIMD, shader clock (GHz) held during the loop */
+int sgpr_probe_mfma_clock(int nacc, int waves_per_simd, int iters, double *out3);
+/* one synthetic C -= A B^T with per-workgroup stamps: TFLOP/s, median k-loop cycles per
+ * workgroup, median shader clock (GHz), k-steps per workgroup */
+int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4);
+/* ablation bits for sgpr_probe_gemm (1 no refetch, 2 no barrier, 4 no fragment reads); 0 = normal */
+int sgpr_probe_gemm_debug(int bits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,11 @@ SIGNATURES = {
     "sgpr_trsm_rlt_dev": (C.c_int, [C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_gemm_nt_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t,
                                    C.c_double, _vp, C.c_size_t, C.c_int, C.c_long, _vp]),
+    "sgpr_probe_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "sgpr_probe_mfma_clock": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
+    "sgpr_probe_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+    "sgpr_probe_gemm_debug": (C.c_int, [C.c_int]),
+    "sgpr_probe_hbm_write": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "sgpr_profile_begin": (C.c_int, []),
     "sgpr_profile_end": (C.c_int, [_dp]),
     "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),

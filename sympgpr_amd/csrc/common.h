@@ -53,6 +53,8 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
             size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,
             hipStream_t st);
 void gemm_profile_begin();
+void gemm_set_stamps(unsigned long long *dev_buf);
+void gemm_set_debug(int bits);
 int gemm_profile_end(double *out8);
 
 // ---- chol.hip : leaf factor / leaf inverse / recursion / solves

@@ -17,6 +17,7 @@
 //     the accumulator then has lane&15 = m (memory-contiguous in column-major C) and
 //     4*reg+(lane>>4) = n, so every C access of a 16-lane quarter is one full 128-B line.
 //     (fp64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg -- NOT the f32 map.)
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -29,6 +30,8 @@ namespace {
 struct ProfRec { hipEvent_t a, b; double flop; int big; };
 struct Prof { bool on = false; std::vector<ProfRec> recs; };
 Prof g_prof;
+int g_dbg = 0;
+unsigned long long *g_stamps = nullptr;  // set by gemm_set_stamps (diagnostics only)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -47,7 +50,52 @@ struct GemmArgs {
     size_t ldc;
     int lower;
     long diag_off;
+    unsigned long long *stamps;  // diagnostic: per-workgroup shader-clock / real-time stamps, or null
+    // tile -> workgroup map (see tile_of): super-tiles of SR x SC tiles, one per XCD at a time
+    int tiles_m, tiles_n, n_sr, n_sc, n_super, tri;
+    int dbg;  // ablation bits for the probe only (results are wrong when set): 1 = no operand
+              // refetch after tile 0, 2 = no in-loop barrier, 4 = no fragment reads in the loop
 };
+
+// Workgroup -> tile map.  The dispatcher deals consecutive workgroup ids round-robin over the 8
+// XCDs, each with a private 4 MiB L2.  Ids that land on one XCD (id % 8 equal) are handed a
+// compact SR x SC block of tiles ("super-tile": 8 x 4 tiles = 2048 x 512 of C for the big
+// kernel), so the 32 workgroups resident on an XCD stream only 8 A-panels + 4 B-panels through
+// its L2 instead of 32 + 32 -- the operand traffic that reaches HBM drops ~5x.  This is a
+// speed-only assumption: any other placement computes the same tiles.
+// `tri`: square SYRK with the diagonal at 0 -- only super-tiles touching the lower triangle are
+// enumerated (column-major over super-columns), so no workgroup slot is spent on an early exit.
+constexpr int SR = 8, SC = 4;
+__device__ __forceinline__ bool tile_of(const GemmArgs &g, int &tile_r, int &tile_c)
+{
+    const int L = blockIdx.x;
+    const int xcd = L & 7, j = L >> 3;
+    const int S = (j / (SR * SC)) * 8 + xcd;
+    if (S >= g.n_super) return false;
+    const int w = j % (SR * SC);
+    int sr, sc;
+    if (!g.tri) {
+        sc = S / g.n_sr;
+        sr = S - sc * g.n_sr;
+    } else {
+        // super-column sc needs super-rows >= sc / R, R = (SR*BM)/(SC*BN) = 4 super-columns per
+        // super-row; columns 4a..4a+3 hold (n_sr - a) super-tiles each.
+        // cum(a) = 4 (a n_sr - a(a-1)/2); find the largest a with cum(a) <= S.
+        const double nsr = (double)g.n_sr;
+        int a = (int)((2.0 * nsr + 1.0 - sqrt((2.0 * nsr + 1.0) * (2.0 * nsr + 1.0) - 2.0 * (double)S)) * 0.5);
+        if (a < 0) a = 0;
+        while (a > 0 && 4 * (a * g.n_sr - a * (a - 1) / 2) > S) --a;
+        while (4 * ((a + 1) * g.n_sr - (a + 1) * a / 2) <= S) ++a;
+        const int rem = S - 4 * (a * g.n_sr - a * (a - 1) / 2);
+        const int per = g.n_sr - a;
+        const int b = rem / per;
+        sc = 4 * a + b;
+        sr = a + (rem - b * per);
+    }
+    tile_r = sr * SR + (w % SR);
+    tile_c = sc * SC + (w / SR);
+    return tile_r < g.tiles_m && tile_c < g.tiles_n;
+}
 
 // Load one (BR x BK) operand tile: element (r, kc) = P[row0 + r + (k0 + kc) * ld], two rows
 // per thread per pass.  FAST: whole tile in range and 16-B aligned -> dwordx4 loads.
@@ -62,14 +110,20 @@ __device__ __forceinline__ void load_tile(const double *P, size_t ld, int row0,
         const int e = p * THREADS + tid;
         const int r = 2 * (e % (BR / 2));
         const int kc = e / (BR / 2);
-        const double *src = P + (size_t)(row0 + r) + (size_t)(k0 + kc) * ld;
         if constexpr (FAST) {
+            const double *src = P + (size_t)(row0 + r) + (size_t)(k0 + kc) * ld;
             reg[p] = *reinterpret_cast<const double2_t *>(src);
         } else {
+            // branch-free edge path: clamp the address into the matrix, zero by select (a
+            // branch per element makes hipcc drain vmcnt(0) between loads)
+            const int kk = min(k0 + kc, kmax - 1);
+            const int r0 = min(row0 + r, rows - 1), r1 = min(row0 + r + 1, rows - 1);
+            const double *col = P + (size_t)kk * ld;
+            const double a = col[r0], b = col[r1];
             const bool kok = (k0 + kc) < kmax;
             double2_t v;
-            v.x = (kok && (row0 + r) < rows) ? src[0] : 0.0;
-            v.y = (kok && (row0 + r + 1) < rows) ? src[1] : 0.0;
+            v.x = (kok && (row0 + r) < rows) ? a : 0.0;
+            v.y = (kok && (row0 + r + 1) < rows) ? b : 0.0;
             reg[p] = v;
         }
     }
@@ -89,21 +143,28 @@ __device__ __forceinline__ void store_tile(double *S, int tid,
     }
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_nt_kernel(const GemmArgs g)
+// one staging pass (a quarter / half of a tile) -> LDS; lets the k-loop slot the writes between MFMAs
+template <int BR, int THREADS>
+__device__ __forceinline__ void store_pass(double *S, int tid, const double2_t &v, int p)
+{
+    const int e = p * THREADS + tid;
+    const int r = 2 * (e % (BR / 2));
+    const int kc = e / (BR / 2);
+    *reinterpret_cast<double2_t *>(S + kc * (BR + PAD) + r) = v;
+}
+
+template <int BM, int BN, bool FAST>
+__device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int tile_r, int tile_c)
 {
     constexpr int WGM = BM / 64, WGN = BN / 64;
     constexpr int THREADS = 64 * WGM * WGN;
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
     constexpr int PA = BM * BK / (2 * THREADS), PB = BN * BK / (2 * THREADS);
     static_assert(PA >= 1 && PB >= 1, "tile too small for the thread count");
-    __shared__ double smem[2 * BK * (LDA_S + LDB_S)];
     double *const sA0 = smem;
     double *const sB0 = smem + 2 * BK * LDA_S;
-
-    const int row0 = blockIdx.x * BM;
-    const int col0 = blockIdx.y * BN;
-    if (g.lower && (long)min(row0 + BM, g.m) - 1 + g.diag_off < (long)col0) return;
+    const int row0 = tile_r * BM;
+    const int col0 = tile_c * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,11 +172,6 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_nt_kernel(con
     const int wm = wave % WGM, wn = wave / WGM;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    // block-uniform: can the interior k-tiles use unpredicated 16-B loads?
-    const bool alignedA = (((uintptr_t)g.A & 15) == 0) && ((g.lda & 1) == 0);
-    const bool alignedB = (((uintptr_t)g.B & 15) == 0) && ((g.ldb & 1) == 0);
-    const bool fullA = alignedA && (row0 + BM <= g.m);
-    const bool fullB = alignedB && (col0 + BN <= g.n);
 
     double4_t acc[4][4];
 #pragma unroll
@@ -125,47 +181,95 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_nt_kernel(con
 
     double2_t ra[PA], rb[PB];
     const int T = (g.k + BK - 1) / BK;
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (g.stamps) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
+    // FAST (block-uniform, decided once in the kernel): every operand tile of this workgroup
+    // is in range and 16-B aligned -> straight-line dwordx4 loads, no branch inside the k-loop.
     auto fetch = [&](int t) {
         const int k0 = t * BK;
-        const bool kfull = k0 + BK <= g.k;
-        if (fullA && kfull) load_tile<BM, THREADS, true>(g.A, g.lda, row0, k0, g.m, g.k, tid, ra);
-        else                load_tile<BM, THREADS, false>(g.A, g.lda, row0, k0, g.m, g.k, tid, ra);
-        if (fullB && kfull) load_tile<BN, THREADS, true>(g.B, g.ldb, col0, k0, g.n, g.k, tid, rb);
-        else                load_tile<BN, THREADS, false>(g.B, g.ldb, col0, k0, g.n, g.k, tid, rb);
+        load_tile<BM, THREADS, FAST>(g.A, g.lda, row0, k0, g.m, g.k, tid, ra);
+        load_tile<BN, THREADS, FAST>(g.B, g.ldb, col0, k0, g.n, g.k, tid, rb);
+    };
+
+    // Software pipeline (one barrier per k-step, placed where every wave still has MFMAs queued):
+    //   top of step t : global loads of tile t+1 go out (register staging, 6 x 16 B per thread)
+    //   kk = 0..3     : 16 MFMAs each on fragment set kk&1 while set (kk+1)&1 is being read
+    //   start of kk=2 : tile t+1 is written to the other LDS buffer (its last reader finished
+    //                   before the previous step's barrier)
+    //   middle of kk=3: barrier; right after it the kk=0 fragments of tile t+1 are read, so the
+    //                   next step starts with its operands already in registers.
+    double fa[2][4], fb[2][4];
+    auto load_frags = [&](int buf, int kk, int set) {
+        if (g.dbg & 4) return;
+        const double *sA = sA0 + buf * BK * LDA_S + wm * 64 + l15 + (kk * 4 + l4) * LDA_S;
+        const double *sB = sB0 + buf * BK * LDB_S + wn * 64 + l15 + (kk * 4 + l4) * LDB_S;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[set][i] = sB[i * 16];  // MFMA A operand <- n side
+            fb[set][i] = sA[i * 16];  // MFMA B operand <- m side
+        }
+    };
+    auto mfma_rows = [&](int set, int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
     };
 
     if (T > 0) {
         fetch(0);
         store_tile<BM, THREADS>(sA0, tid, ra);
         store_tile<BN, THREADS>(sB0, tid, rb);
+        __syncthreads();
+        load_frags(0, 0, 0);
     }
-    __syncthreads();
-
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        if (t + 1 < T) fetch(t + 1);
-        const double *sA = sA0 + cur * BK * LDA_S + wm * 64 + l15;
-        const double *sB = sB0 + cur * BK * LDB_S + wn * 64 + l15;
+        const bool more = (t + 1 < T) && !(g.dbg & 1);
+        if (more) fetch(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 0
+        load_frags(cur, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);  // reads go out FIRST: hipcc otherwise sinks them to 1-2 MFMAs before use
+        mfma_rows(0, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 1
+        load_frags(cur, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 2: tile t+1 goes to the other LDS buffer, a slice of it after every 4 MFMAs
+        load_frags(cur, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        double *const nA = sA0 + (cur ^ 1) * BK * LDA_S;
+        double *const nB = sB0 + (cur ^ 1) * BK * LDB_S;
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double fa[4], fb[4];
+        for (int i = 0; i < 4; ++i) {
+            mfma_rows(0, i, i + 1);
+            if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = sB[(kk * 4 + l4) * LDB_S + i * 16];  // MFMA A operand <- n side
-                fb[i] = sA[(kk * 4 + l4) * LDA_S + i * 16];  // MFMA B operand <- m side
+                for (int p = i * PA / 4; p < (i + 1) * PA / 4; ++p) store_pass<BM, THREADS>(nA, tid, ra[p], p);
+#pragma unroll
+                for (int p = i * PB / 4; p < (i + 1) * PB / 4; ++p) store_pass<BN, THREADS>(nB, tid, rb[p], p);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (t + 1 < T) {
-            store_tile<BM, THREADS>(sA0 + (cur ^ 1) * BK * LDA_S, tid, ra);
-            store_tile<BN, THREADS>(sB0 + (cur ^ 1) * BK * LDB_S, tid, rb);
-        }
-        __syncthreads();
+        // kk = 3
+        mfma_rows(1, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(g.dbg & 2)) __syncthreads();
+        if (more || (g.dbg & 1)) load_frags(cur ^ 1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(1, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    if (g.stamps && tid == 0) {
+        unsigned long long *o = g.stamps + 4 * ((size_t)tile_c * g.tiles_m + tile_r);
+        o[0] = st_c0; o[1] = __builtin_amdgcn_s_memtime();
+        o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
     }
 
     // epilogue: acc[i][j][r] is C(m = row0 + wm*64 + j*16 + l15, n = col0 + wn*64 + i*16 + 4r + l4)
@@ -189,6 +293,195 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64)) void gemm_nt_kernel(con
     }
 }
 
+// ---- fast path: LDS-DMA staging + counted LDS waits -------------------------------------------
+// Interior workgroups (full, 16-B aligned tiles, k % 16 == 0) stage their operands with
+// global_load_lds_dwordx4: one wave-instruction copies 1 KiB = 128 consecutive rows of one k-column
+// straight into the [k][row] LDS image (lane-linear, so the 16-double row pad stays legal), no
+// staging VGPRs, no ds_write, and the copy of tile t+1 is in flight under all 64 MFMAs of tile t.
+// Fragment reads are explicit ds_read_b64 (hipcc fuses neighbouring reads into ds_read2_b64 at
+// half the LDS rate) with counted lgkmcnt waits: 8 reads of the NEXT k-block stay in flight
+// while the current block's MFMAs issue.
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
+}
+template <int OFF>
+__device__ __forceinline__ double ds_read_f64(unsigned addr)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// fragments of k-block KK: fa <- n side (MFMA A operand), fb <- m side (MFMA B operand)
+template <int KK, int LDA_S, int LDB_S>
+__device__ __forceinline__ void read_frags(unsigned aA, unsigned aB, double (&fa)[4], double (&fb)[4])
+{
+    fa[0] = ds_read_f64<(KK * 4 * LDB_S + 0) * 8>(aB);
+    fb[0] = ds_read_f64<(KK * 4 * LDA_S + 0) * 8>(aA);
+    fa[1] = ds_read_f64<(KK * 4 * LDB_S + 16) * 8>(aB);
+    fb[1] = ds_read_f64<(KK * 4 * LDA_S + 16) * 8>(aA);
+    fa[2] = ds_read_f64<(KK * 4 * LDB_S + 32) * 8>(aB);
+    fb[2] = ds_read_f64<(KK * 4 * LDA_S + 32) * 8>(aA);
+    fa[3] = ds_read_f64<(KK * 4 * LDB_S + 48) * 8>(aB);
+    fb[3] = ds_read_f64<(KK * 4 * LDA_S + 48) * 8>(aA);
+}
+#define SGPR_LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, int tile_r, int tile_c)
+{
+    constexpr int WGM = BM / 64, WGN = BN / 64;
+    constexpr int NW = WGM * WGN;
+    constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+    constexpr int QA = BK * (BM / 128) / NW, QB = BK * (BN / 128) / NW;  // DMA instructions per wave
+    static_assert(QA >= 1 && QB >= 1 && BM % 128 == 0 && BN % 128 == 0, "tile / wave count mismatch");
+    double *const sA0 = smem;
+    double *const sB0 = smem + 2 * BK * LDA_S;
+    const int row0 = tile_r * BM, col0 = tile_c * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    double4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+    const int T = g.k / BK;
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (g.stamps) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // this wave's DMA sources (per lane: 2 consecutive rows of one k-column) and LDS row starts
+    const double *srcA[QA], *srcB[QB];
+    int offA[QA], offB[QB];
+#pragma unroll
+    for (int j = 0; j < QA; ++j) {
+        const int q = wave + NW * j, kc = q / (BM / 128), seg = q % (BM / 128);
+        srcA[j] = g.A + (size_t)(row0 + seg * 128 + 2 * lane) + (size_t)kc * g.lda;
+        offA[j] = kc * LDA_S + seg * 128;
+    }
+#pragma unroll
+    for (int j = 0; j < QB; ++j) {
+        const int q = wave + NW * j, kc = q / (BN / 128), seg = q % (BN / 128);
+        srcB[j] = g.B + (size_t)(col0 + seg * 128 + 2 * lane) + (size_t)kc * g.ldb;
+        offB[j] = kc * LDB_S + seg * 128;
+    }
+    const size_t stepA = (size_t)BK * g.lda, stepB = (size_t)BK * g.ldb;
+    auto dma = [&](int t, int buf) {
+        double *dA = sA0 + buf * BK * LDA_S, *dB = sB0 + buf * BK * LDB_S;
+#pragma unroll
+        for (int j = 0; j < QA; ++j)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(srcA[j] + (size_t)t * stepA),
+                (__attribute__((address_space(3))) void *)(dA + offA[j]), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(srcB[j] + (size_t)t * stepB),
+                (__attribute__((address_space(3))) void *)(dB + offB[j]), 16, 0, 0);
+    };
+
+    double fa0[4], fb0[4], fa1[4], fb1[4];
+    auto mfma_rows = [&](const double (&fa)[4], const double (&fb)[4], int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    const unsigned baseA = lds_addr(sA0 + wm * 64 + l15 + l4 * LDA_S);
+    const unsigned baseB = lds_addr(sB0 + wn * 64 + l15 + l4 * LDB_S);
+
+    if (T > 0) {
+        dma(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_frags<0, LDA_S, LDB_S>(baseA, baseB, fa0, fb0);
+    }
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        const bool more = (t + 1 < T) && !(g.dbg & 1);
+        const unsigned aA = baseA + cur * (BK * LDA_S * 8), aB = baseB + cur * (BK * LDB_S * 8);
+        if (more) dma(t + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 0
+        read_frags<1, LDA_S, LDB_S>(aA, aB, fa1, fb1);
+        SGPR_LGKM_WAIT(8);
+        mfma_rows(fa0, fb0, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 1
+        read_frags<2, LDA_S, LDB_S>(aA, aB, fa0, fb0);
+        SGPR_LGKM_WAIT(8);
+        mfma_rows(fa1, fb1, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 2
+        read_frags<3, LDA_S, LDB_S>(aA, aB, fa1, fb1);
+        SGPR_LGKM_WAIT(8);
+        mfma_rows(fa0, fb0, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        // kk = 3: first half, then the step's only barrier, then the next tile's first fragments
+        SGPR_LGKM_WAIT(0);
+        mfma_rows(fa1, fb1, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t+1 has landed
+        if (!(g.dbg & 2)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) {
+            const unsigned nA = baseA + (cur ^ 1) * (BK * LDA_S * 8), nB = baseB + (cur ^ 1) * (BK * LDB_S * 8);
+            read_frags<0, LDA_S, LDB_S>(nA, nB, fa0, fb0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_rows(fa1, fb1, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    SGPR_LGKM_WAIT(0);
+
+    if (g.stamps && tid == 0) {
+        unsigned long long *o = g.stamps + 4 * ((size_t)tile_c * g.tiles_m + tile_r);
+        o[0] = st_c0; o[1] = __builtin_amdgcn_s_memtime();
+        o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // interior tile: no bounds checks.  acc[i][j][r] is C(row0 + wm*64 + j*16 + l15, col0 + wn*64 + i*16 + 4r + l4)
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = col0 + wn * 64 + i * 16 + 4 * r + l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = row0 + wm * 64 + j * 16 + l15;
+                double *c = g.C + (size_t)m + (size_t)n * g.ldc;
+                const double v = alpha * acc[i][j][r];
+                *c = (beta == 0.0) ? v : __builtin_fma(beta, *c, v);
+            }
+        }
+    }
+}
+
+// second launch-bound argument = waves per SIMD: both tile shapes are sized for TWO waves per SIMD
+// (<= 256 VGPRs): one 512-thread workgroup per CU (256x128), or two independent 256-thread
+// workgroups per CU (128x128) whose barriers do not line up.
+template <int BM, int BN>
+__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_nt_kernel(const GemmArgs g)
+{
+    constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+    __shared__ double smem[2 * BK * (LDA_S + LDB_S)];
+    int tile_r, tile_c;
+    if (!tile_of(g, tile_r, tile_c)) return;
+    const int row0 = tile_r * BM, col0 = tile_c * BN;
+    if (g.lower && (long)min(row0 + BM, g.m) - 1 + g.diag_off < (long)col0) return;
+    const bool aligned = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
+    const bool fast = aligned && (row0 + BM <= g.m) && (col0 + BN <= g.n) && (g.k % BK == 0);
+    if (fast && !(g.dbg & 16)) gemm_body_dma<BM, BN>(g, smem, tile_r, tile_c);
+    else if (fast)             gemm_body<BM, BN, true>(g, smem, tile_r, tile_c);
+    else                       gemm_body<BM, BN, false>(g, smem, tile_r, tile_c);
+}
+
 }  // namespace
 
 int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
@@ -201,7 +494,24 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
         set_error("gemm_nt: leading dimension too small");
         return SGPR_E_ARG;
     }
-    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off};
+    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, g_stamps, 0, 0, 0, 0, 0, 0, g_dbg};
+    auto set_map = [&](int bm, int bn) {
+        g.tiles_m = (m + bm - 1) / bm;
+        g.tiles_n = (n + bn - 1) / bn;
+        g.n_sr = (g.tiles_m + SR - 1) / SR;
+        g.n_sc = (g.tiles_n + SC - 1) / SC;
+        // triangular enumeration needs SR*bm == 4*SC*bn (4 super-columns per super-row)
+        g.tri = (lower && diag_off == 0 && m == n && SR * bm == 4 * SC * bn) ? 1 : 0;
+        if (g.tri) {
+            long cnt = 0;
+            for (int sc = 0; sc < g.n_sc; ++sc) cnt += g.n_sr - (sc / 4 < g.n_sr ? sc / 4 : g.n_sr);
+            // the closed form in tile_of assumes every super-column 4a..4a+3 exists
+            if (g.n_sc != 4 * g.n_sr) g.tri = 0;
+            else g.n_super = (int)cnt;
+        }
+        if (!g.tri) g.n_super = g.n_sr * g.n_sc;
+        return (unsigned)(((g.n_super + 7) / 8) * 8 * SR * SC);
+    };
     ProfRec rec{};
     if (g_prof.on) {
         // algorithmic flop of this launch: 2k per updated element (lower: on/below the diagonal)
@@ -221,13 +531,19 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
     }
     // big tile once it yields enough workgroups to fill 256 CUs, small tile below that
     const long big = (long)((m + 255) / 256) * ((n + 127) / 128);
-    if (big >= 256 || (m >= 256 && n == 128)) {
-        const dim3 grid((m + 255) / 256, (n + 127) / 128);
-        if (grid.y > 65535) { set_error("gemm_nt: n too large for one launch"); return SGPR_E_ARG; }
+    // Tile choice, measured on MI355X: at 8192^3 two independent 128x128 workgroups per CU reach
+    // 71.5 TFLOP/s against 69.5 for one 256x128 workgroup (their barriers do not line up), but
+    // inside the n = 131072 factorisation the 256x128 shape wins (61.7 vs 58.4 TFLOP/s overall:
+    // a third less operand traffic per flop, and the triangular tile map below needs its 2:1
+    // aspect).  So: 256x128 whenever it yields >= 256 workgroups, 128x128 below.
+    // SGPR_GEMM_TILE=small forces the 128x128 shape (A/B experiments).
+    static const bool prefer_big = [] { const char *e = getenv("SGPR_GEMM_TILE"); return !(e && e[0] == 's'); }();
+    if (prefer_big && !(g_dbg & 8) && (big >= 256 || (m >= 256 && n == 128))) {
+        const dim3 grid(set_map(256, 128));
         hipLaunchKernelGGL((gemm_nt_kernel<256, 128>), grid, dim3(512), 0, st, g);
         rec.big = 1;
     } else {
-        const dim3 grid((m + 127) / 128, (n + 127) / 128);
+        const dim3 grid(set_map(128, 128));
         hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), grid, dim3(256), 0, st, g);
     }
     SGPR_CHECK_LAUNCH();
@@ -237,6 +553,9 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
     }
     return 0;
 }
+
+void gemm_set_stamps(unsigned long long *dev_buf) { g_stamps = dev_buf; }
+void gemm_set_debug(int bits) { g_dbg = bits; }
 
 void gemm_profile_begin()
 {

@@ -1,0 +1,210 @@
+// probe.hip -- two calibration micro-benchmarks for the roofline denominators (SURVEY.md 8(d):
+// "verify both peaks on the box"): a register-only fp64 MFMA issue loop and a streaming
+// 16-B/lane HBM write.  Measurement aids only; nothing in the fit path calls them.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace sgpr {
+namespace {
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// stamps[4*block + {0,1,2,3}] = shader-clock start/end, 100 MHz real-time start/end (wave 0)
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_clock_kernel(int iters, double *out, unsigned long long *stamps)
+{
+    double4_t acc[NACC];
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)  // asm: keeps hipcc from shuttling the accumulators VGPR<->AGPR
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (s == 12345.678) out[0] = s;
+    if (threadIdx.x == 0) {
+        stamps[4 * blockIdx.x + 0] = t0; stamps[4 * blockIdx.x + 1] = t1;
+        stamps[4 * blockIdx.x + 2] = r0; stamps[4 * blockIdx.x + 3] = r1;
+    }
+}
+
+__global__ __launch_bounds__(256) void mfma_probe_kernel(int iters, double *out)
+{
+    double4_t acc[8];
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;  // keep the chain alive
+}
+
+__global__ __launch_bounds__(256) void write_probe_kernel(double2_t *dst, size_t n2)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const double2_t v{1.0, 2.0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) dst[i] = v;
+}
+}  // namespace
+}  // namespace sgpr
+
+using namespace sgpr;
+
+extern "C" int sgpr_probe_mfma_f64(int waves_per_simd, int iters, double *tflops)
+{
+    double *d = nullptr;
+    SGPR_HIP(hipMalloc((void **)&d, 64));
+    hipEvent_t a, b;
+    SGPR_HIP(hipEventCreate(&a));
+    SGPR_HIP(hipEventCreate(&b));
+    const int blocks = 256 * waves_per_simd;  // 256-thread blocks: one wave per SIMD each
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, nullptr, iters / 10 + 1, d);
+    SGPR_HIP(hipEventRecord(a, nullptr));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, nullptr, iters, d);
+    SGPR_HIP(hipEventRecord(b, nullptr));
+    SGPR_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    SGPR_HIP(hipEventElapsedTime(&ms, a, b));
+    *tflops = (double)blocks * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
+    return 0;
+}
+
+// out3: [0] TFLOP/s (event-timed), [1] shader cycles per MFMA per SIMD (median block),
+//       [2] shader clock in GHz held during the loop (median block)
+extern "C" int sgpr_probe_mfma_clock(int nacc, int waves_per_simd, int iters, double *out3)
+{
+    const int blocks = 256 * waves_per_simd;
+    double *d = nullptr;
+    unsigned long long *st = nullptr;
+    SGPR_HIP(hipMalloc((void **)&d, 64));
+    SGPR_HIP(hipMalloc((void **)&st, sizeof(unsigned long long) * 4 * blocks));
+    hipEvent_t a, b;
+    SGPR_HIP(hipEventCreate(&a));
+    SGPR_HIP(hipEventCreate(&b));
+    auto launch = [&](int it) {
+        if (nacc == 4) hipLaunchKernelGGL((mfma_clock_kernel<4>), dim3(blocks), dim3(256), 0, nullptr, it, d, st);
+        else if (nacc == 16) hipLaunchKernelGGL((mfma_clock_kernel<16>), dim3(blocks), dim3(256), 0, nullptr, it, d, st);
+        else hipLaunchKernelGGL((mfma_clock_kernel<8>), dim3(blocks), dim3(256), 0, nullptr, it, d, st);
+    };
+    if (nacc != 4 && nacc != 16) nacc = 8;
+    launch(iters);  // warm / ramp the clocks
+    SGPR_HIP(hipEventRecord(a, nullptr));
+    launch(iters);
+    SGPR_HIP(hipEventRecord(b, nullptr));
+    SGPR_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    SGPR_HIP(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> h(4 * (size_t)blocks);
+    SGPR_HIP(hipMemcpy(h.data(), st, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> cyc(blocks), ghz(blocks);
+    for (int i = 0; i < blocks; ++i) {
+        const double dc = (double)(h[4 * i + 1] - h[4 * i]), dr = (double)(h[4 * i + 3] - h[4 * i + 2]);
+        cyc[i] = dc / ((double)iters * nacc) / waves_per_simd;  // per SIMD: waves_per_simd waves share the pipe
+        ghz[i] = dr > 0 ? dc / (dr * 10.0) : 0.0;              // 100 MHz real-time ticks -> 10 ns each
+    }
+    std::sort(cyc.begin(), cyc.end());
+    std::sort(ghz.begin(), ghz.end());
+    out3[0] = (double)blocks * 4 * iters * nacc * 2048.0 / (ms * 1e-3) / 1e12;
+    out3[1] = cyc[blocks / 2];
+    out3[2] = ghz[blocks / 2];
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d); (void)hipFree(st);
+    return 0;
+}
+
+extern "C" int sgpr_probe_hbm_write(size_t bytes, int reps, double *gbs)
+{
+    double *d = nullptr;
+    SGPR_HIP(hipMalloc((void **)&d, bytes));
+    hipEvent_t a, b;
+    SGPR_HIP(hipEventCreate(&a));
+    SGPR_HIP(hipEventCreate(&b));
+    hipLaunchKernelGGL(write_probe_kernel, dim3(2048), dim3(256), 0, nullptr, (double2_t *)d, bytes / 16);
+    SGPR_HIP(hipEventRecord(a, nullptr));
+    for (int r = 0; r < reps; ++r)
+        hipLaunchKernelGGL(write_probe_kernel, dim3(2048), dim3(256), 0, nullptr, (double2_t *)d, bytes / 16);
+    SGPR_HIP(hipEventRecord(b, nullptr));
+    SGPR_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    SGPR_HIP(hipEventElapsedTime(&ms, a, b));
+    *gbs = (double)bytes * reps / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(d);
+    return 0;
+}
+
+// Diagnostic: run one C -= A B^T (m x n x k, synthetic operands) with per-workgroup stamps and
+// report [0] TFLOP/s (event), [1] median shader cycles a workgroup spent in its k-loop,
+// [2] median shader clock (GHz) during it, [3] k-steps (of 16) per workgroup.
+extern "C" int sgpr_probe_gemm_debug(int bits) { gemm_set_debug(bits); return 0; }
+
+extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
+{
+    double *A = nullptr, *B = nullptr, *Cm = nullptr;
+    unsigned long long *st = nullptr;
+    SGPR_HIP(hipMalloc((void **)&A, sizeof(double) * (size_t)m * k));
+    SGPR_HIP(hipMalloc((void **)&B, sizeof(double) * (size_t)n * k));
+    SGPR_HIP(hipMalloc((void **)&Cm, sizeof(double) * (size_t)m * n));
+    const size_t nwg = (size_t)((m + 127) / 128 + 8) * ((n + 127) / 128 + 8);
+    SGPR_HIP(hipMalloc((void **)&st, sizeof(unsigned long long) * 4 * nwg));
+    SGPR_HIP(hipMemset(st, 0, sizeof(unsigned long long) * 4 * nwg));
+    // random-ish operands (not zeros: DVFS reads high on trivial data)
+    KConst kc;
+    const double hyp[3] = {0.7, 0.9, 1.0};
+    make_kconst(SGPR_FAM_C, hyp, 3, &kc);
+    std::vector<double> h((size_t)std::max(m, n) + k);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = 0.37 * (double)((i * 2654435761u) % 1000) / 100.0;
+    double *pts = nullptr;
+    SGPR_HIP(hipMalloc((void **)&pts, sizeof(double) * h.size()));
+    SGPR_HIP(hipMemcpy(pts, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+    gram_reg(SGPR_FAM_C, m, k, pts, pts, pts + 3, pts + 5, kc, A, m, 0, 0.0, nullptr);
+    gram_reg(SGPR_FAM_C, n, k, pts, pts + 1, pts + 2, pts + 7, kc, B, n, 0, 0.0, nullptr);
+    SGPR_HIP(hipMemset(Cm, 0, sizeof(double) * (size_t)m * n));
+    hipEvent_t a, b;
+    SGPR_HIP(hipEventCreate(&a));
+    SGPR_HIP(hipEventCreate(&b));
+    int rc = gemm_nt(m, n, k, -1.0, A, m, B, n, 1.0, Cm, m, lower, 0, nullptr);  // warm
+    if (rc) return rc;
+    gemm_set_stamps(st);
+    SGPR_HIP(hipEventRecord(a, nullptr));
+    rc = gemm_nt(m, n, k, -1.0, A, m, B, n, 1.0, Cm, m, lower, 0, nullptr);
+    SGPR_HIP(hipEventRecord(b, nullptr));
+    gemm_set_stamps(nullptr);
+    if (rc) return rc;
+    SGPR_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    SGPR_HIP(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> hs(4 * nwg);
+    SGPR_HIP(hipMemcpy(hs.data(), st, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> cyc, ghz;
+    for (size_t i = 0; i < nwg; ++i) {
+        if (hs[4 * i + 1] == 0) continue;
+        const double dc = (double)(hs[4 * i + 1] - hs[4 * i]), dr = (double)(hs[4 * i + 3] - hs[4 * i + 2]);
+        cyc.push_back(dc);
+        if (dr > 0) ghz.push_back(dc / (dr * 10.0));
+    }
+    std::sort(cyc.begin(), cyc.end());
+    std::sort(ghz.begin(), ghz.end());
+    double flop = 2.0 * m * n * (double)k;
+    if (lower) flop *= 0.5;
+    out4[0] = flop / (ms * 1e-3) / 1e12;
+    out4[1] = cyc.empty() ? 0 : cyc[cyc.size() / 2];
+    out4[2] = ghz.empty() ? 0 : ghz[ghz.size() / 2];
+    out4[3] = (k + 15) / 16;
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(Cm); (void)hipFree(st); (void)hipFree(pts);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
