@@ -26,6 +26,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+METRIC = "Gram-build GB/s + Cholesky fp64 TFLOP/s at N=65536 d=2; |alpha-alpha_ref|/|alpha_ref|"
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 MFMA_F64_PEAK_TF = 78.6   # MI355X fp64 matrix peak, vendor spec
 
@@ -90,6 +91,8 @@ def main():
     ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2N)")
     ap.add_argument("--family", default="A")
     ap.add_argument("--cpu-sample", type=int, default=4096, help="N of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--nb", type=int, default=1024, help="block size of the multi-GPU block-cyclic layout")
+    ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
     ap.add_argument("--full-matrix", action="store_true", help="build all of K, not only the lower triangle")
     args = ap.parse_args()
 
@@ -118,9 +121,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            import torch.distributed as dist
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         from sympgpr_amd.dist_bench import run_distributed
-        return run_distributed(args, rank, local_rank, world)
+        return run_distributed(args, rank, local_rank, world, synth, METRIC,
+                               {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS})
 
     n_pts = args.n_pts
     n = 2 * n_pts
@@ -156,11 +165,11 @@ def main():
     gram_bytes = 8.0 * n * (n + 1) / 2 if not args.full_matrix else 8.0 * n * n
     chol_flop = n**3 / 3.0
     out = {
-        "metric": "Gram-build GB/s + Cholesky fp64 TFLOP/s at N=65536 d=2; |alpha-alpha_ref|/|alpha_ref|",
+        "metric": METRIC,
         "value": chol_flop / (ms_per_step * 1e-3) / 1e12,
         "unit": "TFLOP/s (n^3/3 flop over the whole step: Gram build + Cholesky + solve)",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": "synthetic d=2 N=%d: matrix order n=%d (%.1f GB fp64), family %s, "
                                "l=2*sqrt(12pi/N), sig2n=1e-2/l^2" % (n_pts, n, 8.0 * n * n / 1e9, args.family),

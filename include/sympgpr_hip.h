@@ -150,6 +150,28 @@ int sgpr_trsm_rlt_dev(int m, int n, const double *L, size_t ldl, double *B, size
 int sgpr_gemm_nt_dev(int m, int n, int k, double alpha, const double *A, size_t lda,
                      const double *B, size_t ldb, double beta, double *C, size_t ldc, int lower,
                      long diag_off, void *stream);
+/* SYRK-style update of a LOCAL piece of a 2-D block-cyclic matrix: as sgpr_gemm_nt_dev with
+ * lower != 0, but a tile is computed iff it touches a block on/below the GLOBAL diagonal:
+ * (row / blk) * pr + pi >= (col / blk) * pc + pj   (blk = block size, (pr, pc) = process grid,
+ * (pi, pj) = this rank's grid coordinates plus the block offsets of C's first row / column). */
+int sgpr_gemm_nt_bc_dev(int m, int n, int k, double alpha, const double *A, size_t lda,
+                        const double *B, size_t ldb, double beta, double *C, size_t ldc, int blk,
+                        int pr, int pi, int pc, int pj, void *stream);
+/* b (n) := L^-1 b (trans = 0) or L^-T b (trans != 0); `work` as left by sgpr_potrf_dev on L */
+int sgpr_trsv_dev(int n, const double *L, size_t ldl, const void *work, double *b, int trans,
+                  void *stream);
+/* y -= A x (trans = 0: A m x k, x k, y m) or y -= A^T x (trans != 0: x m, y k) */
+int sgpr_gemv_sub_dev(int trans, int m, int k, const double *A, size_t lda, const double *x,
+                      double *y, void *stream);
+/* K*(2 x 2 n0) . alpha for m test points, everything device-resident (sympgpr.f90:75-86 calcq,
+ * :112-124 target of calcP, with alpha = Kyinv ztrain cached): out_p = row 1, out_q = row 2 */
+int sgpr_predict_rows_dev(int family, int m, const double *q, const double *P, int n0,
+                          const double *xtrain, const double *ytrain, const double *hyp, int nhyp,
+                          const double *alpha, double *out_p, double *out_q, void *stream);
+/* Kstar(1 x n0) . alpha with the scalar kernel (sympgpr.f90:62-73 guessP) */
+int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, int n0,
+                         const double *xtrain, const double *ytrain, const double *hyp, int nhyp,
+                         const double *alpha, double *out, void *stream);
 /* alpha-solve on device with the factor and its leaf inverses: b (n) := L^-T L^-1 b */
 int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b,
                        void *stream);

@@ -503,6 +503,56 @@ int sgpr_gemm_nt_dev(int m, int n, int k, double alpha, const double *A, size_t 
                    static_cast<hipStream_t>(stream));
 }
 
+int sgpr_gemm_nt_bc_dev(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+                        size_t ldb, double beta, double *C, size_t ldc, int blk, int pr, int pi, int pc,
+                        int pj, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    const int bc[5] = {blk, pr, pi, pc, pj};
+    return gemm_nt_bc(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 1, bc, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_trsv_dev(int n, const double *L, size_t ldl, const void *work, double *b, int trans, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return trsv(n, L, ldl, work, b, trans, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_gemv_sub_dev(int trans, int m, int k, const double *A, size_t lda, const double *x, double *y,
+                      void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (m < 0 || k < 0 || (m > 0 && lda < (size_t)m)) { set_error("gemv: bad shape"); return SGPR_E_ARG; }
+    return trans ? gemv_t_sub(m, k, A, lda, x, y, static_cast<hipStream_t>(stream))
+                 : gemv_n_sub(m, k, A, lda, x, y, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_predict_rows_dev(int family, int m, const double *q, const double *P, int n0, const double *xtrain,
+                          const double *ytrain, const double *hyp, int nhyp, const double *alpha,
+                          double *out_p, double *out_q, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    return predict_rows(family, m, q, P, n0, xtrain, ytrain, kc, alpha, out_p, out_q,
+                        static_cast<hipStream_t>(stream));
+}
+
+int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, int n0, const double *xtrain,
+                         const double *ytrain, const double *hyp, int nhyp, const double *alpha,
+                         double *out, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    return predict_reg(family, m, q, P, n0, xtrain, ytrain, kc, alpha, out, static_cast<hipStream_t>(stream));
+}
+
 int sgpr_profile_begin(void) { gemm_profile_begin(); return 0; }
 int sgpr_profile_end(double *out8)
 {

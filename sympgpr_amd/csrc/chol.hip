@@ -240,6 +240,14 @@ int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, h
     return trsv_t_rec(n, L, ldl, b, 0, c);
 }
 
+// one-sided solve: b := L^-1 b (trans = 0) or L^-T b (trans = 1)
+int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
+    return trans ? trsv_t_rec(n, L, ldl, b, 0, c) : trsv_n_rec(n, L, ldl, b, 0, c);
+}
+
 // leaf inverses of an existing factor (for solves against an L that was not produced by potrf())
 int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st)
 {

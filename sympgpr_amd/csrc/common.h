@@ -52,6 +52,9 @@ int predict_reg(int family, int m, const double *q, const double *P, int n0, con
 int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
             size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,
             hipStream_t st);
+int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+               size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc5,
+               hipStream_t st);
 void gemm_profile_begin();
 void gemm_set_stamps(unsigned long long *dev_buf);
 void gemm_set_debug(int bits);
@@ -64,6 +67,7 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
              hipStream_t st);
 int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st);
+int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st);
 int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st);
 
 // ---- blas_small.hip

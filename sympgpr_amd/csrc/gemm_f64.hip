@@ -53,6 +53,10 @@ struct GemmArgs {
     unsigned long long *stamps;  // diagnostic: per-workgroup shader-clock / real-time stamps, or null
     // tile -> workgroup map (see tile_of): super-tiles of SR x SC tiles, one per XCD at a time
     int tiles_m, tiles_n, n_sr, n_sc, n_super, tri;
+    // lower-mode skip test in block-cyclic form: a tile is needed iff
+    //   (last_row / lblk) * lpr + lpi >= (first_col / lblk) * lpc + lpj
+    // single GPU: lblk = 1, lpr = lpc = 1, lpi = diag_off, lpj = 0  (row + diag_off >= col)
+    int lblk, lpr, lpi, lpc, lpj;
     int dbg;  // ablation bits for the probe only (results are wrong when set): 1 = no operand
               // refetch after tile 0, 2 = no in-loop barrier, 4 = no fragment reads in the loop
 };
@@ -474,7 +478,10 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_nt_kernel(
     int tile_r, tile_c;
     if (!tile_of(g, tile_r, tile_c)) return;
     const int row0 = tile_r * BM, col0 = tile_c * BN;
-    if (g.lower && (long)min(row0 + BM, g.m) - 1 + g.diag_off < (long)col0) return;
+    if (g.lower) {
+        const long rb = ((long)min(row0 + BM, g.m) - 1) / g.lblk, cb = (long)col0 / g.lblk;
+        if (rb * g.lpr + g.lpi < cb * g.lpc + g.lpj) return;
+    }
     const bool aligned = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
     const bool fast = aligned && (row0 + BM <= g.m) && (col0 + BN <= g.n) && (g.k % BK == 0);
     if (fast && !(g.dbg & 16)) gemm_body_dma<BM, BN>(g, smem, tile_r, tile_c);
@@ -488,13 +495,26 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
             size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,
             hipStream_t st)
 {
+    const int bc[5] = {1, 1, (int)diag_off, 1, 0};
+    return gemm_nt_bc(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, bc, st);
+}
+
+// `bc` = {blk, pr, pi, pc, pj}: the block-cyclic form of the lower-mode skip test (GemmArgs)
+int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+               size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc,
+               hipStream_t st)
+{
+    const bool plain = bc[0] == 1 && bc[1] == 1 && bc[3] == 1 && bc[4] == 0;
+    const long diag_off = plain ? bc[2] : 1;  // != 0 disables the triangular tile enumeration
+    if (bc[0] < 1 || bc[1] < 1 || bc[3] < 1) { set_error("gemm_nt: bad block-cyclic descriptor"); return SGPR_E_ARG; }
     if (m < 0 || n < 0 || k < 0) { set_error("gemm_nt: negative extent"); return SGPR_E_ARG; }
     if (m == 0 || n == 0) return 0;
     if (lda < (size_t)m || ldb < (size_t)n || ldc < (size_t)m) {
         set_error("gemm_nt: leading dimension too small");
         return SGPR_E_ARG;
     }
-    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, g_stamps, 0, 0, 0, 0, 0, 0, g_dbg};
+    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, g_stamps, 0, 0, 0, 0, 0, 0,
+               bc[0], bc[1], bc[2], bc[3], bc[4], g_dbg};
     auto set_map = [&](int bm, int bn) {
         g.tiles_m = (m + bm - 1) / bm;
         g.tiles_n = (n + bn - 1) / bn;
@@ -516,7 +536,7 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
     if (g_prof.on) {
         // algorithmic flop of this launch: 2k per updated element (lower: on/below the diagonal)
         double elems = (double)m * n;
-        if (lower) {
+        if (lower && plain) {
             elems = 0.0;
             for (int j = 0; j < n; ++j) {
                 long first = (long)j - diag_off;  // first row with row + diag_off >= col

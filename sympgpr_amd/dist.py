@@ -1,0 +1,316 @@
+"""2-D block-cyclic Gram build + Cholesky + alpha across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests).  The matrix Ky (order n = 2N) is cut into nb x nb blocks; block (I, J) lives
+on grid position (I mod pr, J mod pc).  Per panel step K of the right-looking factorisation:
+
+    owner of (K,K):      factor the diagonal block (sgpr_potrf_dev)
+    process column K%pc: receives L_KK + its leaf inverses, solves its panel pieces
+                         L(I,K) = A(I,K) L_KK^-T (sgpr_trsm_rlt_dev)
+    everyone:            pr broadcasts deliver the panel pieces of the pr process rows (RCCL
+                         broadcast over xGMI); the pieces needed as the column operand are
+                         regrouped by block
+    everyone:            local trailing update A(I,J) -= L(I,K) L(J,K)^T on the blocks it owns,
+                         one sgpr_gemm_nt_bc_dev call (fp64 MFMA), tiles above the global
+                         diagonal skipped
+
+The Gram build needs no communication: every rank evaluates exactly the pairs of the blocks it
+owns (inputs are replicated, 16 N bytes).  The triangular solves keep b replicated and exchange
+one nb-vector reduce + one broadcast per block step.
+
+This mirrors, for N beyond one GPU's HBM, the body of nll_chol (python/functions/func.py:189-196
+of the reference), which has no parallel form of its own.
+
+The numerical work is delegated to an `ops` object: `HipOps` (below) binds the C ABI on torch
+CUDA tensors and is the only product backend; tests/ supply a NumPy backend to exercise the
+distribution logic under gloo without a GPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+def grid_shape(world):
+    """pr x pc process grid, pr >= pc, as square as the factorisation allows."""
+    pc = int(math.isqrt(world))
+    while world % pc:
+        pc -= 1
+    return world // pc, pc
+
+
+def _count_le(K, p, nproc):
+    """number of block indices I = p, p+nproc, ... with I <= K"""
+    return 0 if K < p else (K - p) // nproc + 1
+
+
+class HipOps:
+    """Block operations on torch CUDA tensors through libsympgpr_hip.so (device pointers)."""
+
+    device_type = "cuda"
+
+    def __init__(self, device):
+        self.lib = L.load_library()
+        self.device = device
+        L.check(self.lib.sgpr_set_device(device.index or 0))
+
+    def empty(self, n, dtype=torch.float64):
+        return torch.empty(n, dtype=dtype, device=self.device)
+
+    def zeros(self, n, dtype=torch.float64):
+        return torch.zeros(n, dtype=dtype, device=self.device)
+
+    @staticmethod
+    def _p(t, off=0):
+        return C.c_void_p(t.data_ptr() + 8 * off)
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def work_size(self, nb):
+        return (self.lib.sgpr_potrf_workspace(nb) + 7) // 8  # in doubles
+
+    def gram_pairs(self, fam, mi, mj, xb, yb, xa, ya, hyp, A, offs, ld, flags):
+        """offs: element offsets of the qq / Pq / qP / PP parts inside A (or None)."""
+        hyp = L.f64(hyp)
+        ptr = [self._p(A, o) if o is not None else None for o in offs]
+        L.check(self.lib.sgpr_gram_pairs_dev(L.family_id(fam), mi, mj, self._p(xb), self._p(yb), self._p(xa),
+                                             self._p(ya), L.dptr(hyp), len(hyp), ptr[0], ptr[1], ptr[2], ptr[3],
+                                             ld, 0, 0.0, flags, self.stream()), "sgpr_gram_pairs_dev")
+
+    def potrf(self, nb, A, work, info):
+        L.check(self.lib.sgpr_potrf_dev(nb, self._p(A), nb, self._p(work), 8 * work.numel(), self._p(info),
+                                        self.stream()), "sgpr_potrf_dev")
+
+    def trsm(self, m, nb, Lkk, work, B, boff, ldb):
+        L.check(self.lib.sgpr_trsm_rlt_dev(m, nb, self._p(Lkk), nb, self._p(B, boff), ldb, self._p(work),
+                                           self.stream()), "sgpr_trsm_rlt_dev")
+
+    def syrk_update(self, m, n, k, A, lda, B, ldb, Cm, coff, ldc, blk, pr, pi, pc, pj):
+        L.check(self.lib.sgpr_gemm_nt_bc_dev(m, n, k, -1.0, self._p(A), lda, self._p(B), ldb, 1.0,
+                                             self._p(Cm, coff), ldc, blk, pr, pi, pc, pj, self.stream()),
+                "sgpr_gemm_nt_bc_dev")
+
+    def trsv(self, nb, Lkk, work, b, trans):
+        L.check(self.lib.sgpr_trsv_dev(nb, self._p(Lkk), nb, self._p(work), self._p(b), trans, self.stream()),
+                "sgpr_trsv_dev")
+
+    def gemv_sub(self, trans, m, k, A, aoff, lda, x, y):
+        L.check(self.lib.sgpr_gemv_sub_dev(trans, m, k, self._p(A, aoff), lda, self._p(x), self._p(y),
+                                           self.stream()), "sgpr_gemv_sub_dev")
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+class DistFit:
+    """Ky = build_K(x,x) + |sig2n| I, L, alpha, nll on a pr x pc grid.  All ranks call every
+    method collectively."""
+
+    _BIG = 1 << 60
+
+    def __init__(self, ops, family, x, y, z, hyp, sig2n, nb=1024, group=None):
+        self.ops, self.family = ops, family
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group
+        self.pr, self.pc = grid_shape(self.world)
+        self.pi, self.pj = self.rank % self.pr, self.rank // self.pr
+        self.N = len(x)
+        self.n = 2 * self.N
+        self.nb = nb
+        if self.N % nb:
+            raise ValueError("the number of training points must be a multiple of the block size nb")
+        self.nbk = self.n // nb
+        nbN = self.N // nb
+        if nbN % self.pr or nbN % self.pc:
+            raise ValueError("N/nb = %d must be a multiple of the grid dimensions %dx%d" % (nbN, self.pr, self.pc))
+        self.hyp = np.asarray(hyp, dtype=np.float64)
+        self.sig2n = abs(float(sig2n))
+        self.rows = list(range(self.pi, self.nbk, self.pr))   # global block rows held here
+        self.cols = list(range(self.pj, self.nbk, self.pc))
+        self.mloc, self.nloc = len(self.rows) * nb, len(self.cols) * nb
+        self.x = np.asarray(x, dtype=np.float64)
+        self.y = np.asarray(y, dtype=np.float64)
+        self.z = torch.as_tensor(np.asarray(z, dtype=np.float64)).to(ops.device)
+        # local matrix, column-major (mloc x nloc), as a flat tensor
+        self.A = ops.empty(self.mloc * self.nloc)
+        self.A2 = self.A.view(self.nloc, self.mloc)            # [local col, local row]
+        self.Lkk = ops.empty(nb * nb)
+        self.work = {}                                         # K -> leaf inverses of L_KK (owner only)
+        self.wbuf = ops.empty(ops.work_size(nb))
+        self.info_t = ops.zeros(2, dtype=torch.int32)
+        # process-column / process-row groups (every rank creates all of them, same order)
+        self.col_groups = [dist.new_group([q + c * self.pr for q in range(self.pr)]) for c in range(self.pc)]
+        self.row_groups = [dist.new_group([r + c * self.pr for c in range(self.pc)]) for r in range(self.pr)]
+        self.alpha = None
+        self.nll = None
+        self.info = 0
+
+    def grank(self, pi, pj):
+        return pi + pj * self.pr
+
+    # ------------------------------------------------------------------ Gram build (no comm)
+    def build(self):
+        """Each rank evaluates the pairs of its own blocks.  Local rows are the q-rows of its
+        block rows followed by their P-rows (N/nb is a multiple of pr, pc), so the local matrix
+        is again [[qq, qP], [Pq, PP]] over the SELECTED row / column points."""
+        ops, nb, N = self.ops, self.nb, self.N
+        nbN = N // nb
+        rsel = np.concatenate([np.arange(I * nb, (I + 1) * nb) for I in self.rows if I < nbN])
+        csel = np.concatenate([np.arange(J * nb, (J + 1) * nb) for J in self.cols if J < nbN])
+        dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ops.device)
+        xb, yb, xa, ya = dev(self.x[rsel]), dev(self.y[rsel]), dev(self.x[csel]), dev(self.y[csel])
+        mi, mj = len(rsel), len(csel)
+        ld = self.mloc
+        offs = [0, mi, mj * ld, mi + mj * ld]   # qq, Pq, qP, PP
+        ops.gram_pairs(self.family, mi, mj, xb, yb, xa, ya, self.hyp, self.A, offs, ld, L.G_ALL)
+        # |sig2n| on the global diagonal: the diagonal blocks this rank owns
+        for li, I in enumerate(self.rows):
+            if I % self.pc == self.pj:
+                lj = I // self.pc
+                blk = self.A2[lj * nb:(lj + 1) * nb, li * nb:(li + 1) * nb]
+                blk.diagonal().add_(self.sig2n)
+
+    # ------------------------------------------------------------------ factorisation
+    def factor(self):
+        ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
+        self.info = 0
+        self.fail_t = torch.full((1,), self._BIG, dtype=torch.int64, device=self.info_t.device)
+        for K in range(self.nbk):
+            kI, kJ = K % pr, K % pc
+            lj_K = K // pc
+            # (1) diagonal block
+            if (pi, pj) == (kI, kJ):
+                li_K = K // pr
+                blk = self.A2[lj_K * nb:(lj_K + 1) * nb, li_K * nb:(li_K + 1) * nb]
+                self.Lkk.view(nb, nb).copy_(blk)
+                ops.potrf(nb, self.Lkk, self.wbuf, self.info_t)
+                # LAPACK-style global index of the first failing minor, tracked on the device
+                cand = torch.where(self.info_t[:1] != 0, self.info_t[:1].to(torch.int64) + K * nb,
+                                   torch.full_like(self.fail_t, self._BIG))
+                self.fail_t = torch.minimum(self.fail_t, cand)
+                blk.copy_(self.Lkk.view(nb, nb))
+                self.work[K] = self.wbuf.clone()
+            # (2) panel solve on process column kJ
+            li0 = _count_le(K, pi, pr)            # first local block row with I > K
+            m_p = self.mloc - li0 * nb
+            if pj == kJ:
+                src = self.grank(kI, kJ)
+                dist.broadcast(self.Lkk, src=src, group=self.col_groups[kJ])
+                dist.broadcast(self.wbuf, src=src, group=self.col_groups[kJ])
+                if m_p > 0:
+                    ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, li0 * nb + lj_K * nb * self.mloc, self.mloc)
+            # (3) panel pieces of every process row -> everyone
+            pieces = []
+            for q in range(pr):
+                lq0 = _count_le(K, q, pr)
+                nblk_q = len(range(q, self.nbk, pr)) - lq0
+                P = ops.empty(nblk_q * nb * nb)
+                if nblk_q > 0:
+                    if (pi, pj) == (q, kJ):
+                        P.view(nb, nblk_q * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, lq0 * nb:])
+                    dist.broadcast(P, src=self.grank(q, kJ), group=self.group)
+                pieces.append((P, nblk_q, lq0))
+            # (4) operands of the local update
+            Lrow, nrow_blk, _ = pieces[pi]
+            lj0 = _count_le(K, pj, pc)            # first local block column with J > K
+            ncol_blk = len(self.cols) - lj0
+            if nrow_blk == 0 or ncol_blk == 0:
+                continue
+            Lcol = ops.empty(ncol_blk * nb * nb)
+            Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
+            for q in range(pr):
+                P, nblk_q, lq0 = pieces[q]
+                if nblk_q == 0:
+                    continue
+                t_idx, p_idx = [], []
+                for t in range(ncol_blk):
+                    J = self.cols[lj0 + t]
+                    if J % pr == q:
+                        t_idx.append(t)
+                        p_idx.append(J // pr - lq0)
+                if t_idx:
+                    ti = torch.as_tensor(t_idx, device=Lcol.device)
+                    pidx = torch.as_tensor(p_idx, device=Lcol.device)
+                    Lc3[:, ti, :] = P.view(nb, nblk_q, nb)[:, pidx, :]
+            # (5) A(I,J) -= L(I,K) L(J,K)^T on the local blocks with I, J > K
+            m, n = nrow_blk * nb, ncol_blk * nb
+            ops.syrk_update(m, n, nb, Lrow, m, Lcol, n, self.A, li0 * nb + lj0 * nb * self.mloc, self.mloc,
+                            nb, pr, li0 * pr + pi, pc, lj0 * pc + pj)
+        t = self.fail_t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        v = int(t.item())
+        self.info = 0 if v >= self._BIG else v
+        return self.info
+
+    # ------------------------------------------------------------------ solves
+    def _diag_block(self, K):
+        li, lj = K // self.pr, K // self.pc
+        nb = self.nb
+        self.Lkk.view(nb, nb).copy_(self.A2[lj * nb:(lj + 1) * nb, li * nb:(li + 1) * nb])
+        return self.Lkk
+
+    def solve(self):
+        """alpha = L^-T L^-1 z (replicated result), nll = z.alpha/2 + sum log diag L."""
+        ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
+        b = self.z.clone()
+        b2 = b.view(self.nbk, nb)
+        pend = ops.zeros(self.mloc)
+        vec = ops.empty(nb)
+        logdet = ops.zeros(1)
+        # forward: y_K = L_KK^-1 (b_K - sum_{J<K} L(K,J) y_J)
+        for K in range(self.nbk):
+            kI, kJ = K % pr, K % pc
+            owner = self.grank(kI, kJ)
+            if pi == kI:
+                li_K = K // pr
+                vec.copy_(pend[li_K * nb:(li_K + 1) * nb])
+                dist.reduce(vec, dst=owner, op=dist.ReduceOp.SUM, group=self.row_groups[kI])
+            if self.rank == owner:
+                vec.neg_().add_(b2[K])
+                Lkk = self._diag_block(K)
+                logdet += torch.log(Lkk.view(nb, nb).diagonal()).sum()
+                ops.trsv(nb, Lkk, self.work[K], vec, 0)
+            dist.broadcast(vec, src=owner, group=self.group)
+            b2[K].copy_(vec)
+            if pj == kJ:
+                li0 = _count_le(K, pi, pr)
+                m_p = self.mloc - li0 * nb
+                if m_p > 0:
+                    # pend[rows I > K] += L(I,K) y_K   (gemv_sub subtracts: feed -y)
+                    ops.gemv_sub(0, m_p, nb, self.A, li0 * nb + (K // pc) * nb * self.mloc, self.mloc,
+                                 -vec, pend[li0 * nb:])
+        # backward: x_K = L_KK^-T (y_K - sum_{I>K} L(I,K)^T x_I)
+        rows_t = torch.as_tensor(self.rows, device=b.device)
+        for K in range(self.nbk - 1, -1, -1):
+            kI, kJ = K % pr, K % pc
+            owner = self.grank(kI, kJ)
+            if pj == kJ:
+                vec.zero_()
+                li0 = _count_le(K, pi, pr)
+                m_p = self.mloc - li0 * nb
+                if m_p > 0:
+                    xloc = b2[rows_t[li0:]].reshape(-1).contiguous()
+                    # vec -= L_panel^T xloc  -> vec = -(sum)
+                    ops.gemv_sub(1, m_p, nb, self.A, li0 * nb + (K // pc) * nb * self.mloc, self.mloc, xloc, vec)
+                dist.reduce(vec, dst=owner, op=dist.ReduceOp.SUM, group=self.col_groups[kJ])
+            if self.rank == owner:
+                vec.add_(b2[K])
+                ops.trsv(nb, self._diag_block(K), self.work[K], vec, 1)
+            dist.broadcast(vec, src=owner, group=self.group)
+            b2[K].copy_(vec)
+        dist.all_reduce(logdet, op=dist.ReduceOp.SUM, group=self.group)
+        self.alpha = b
+        self.nll = float((0.5 * torch.dot(self.z, b) + logdet[0]).item())
+        return b
+
+    def run(self):
+        self.build()
+        info = self.factor()
+        if info:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % info)
+        return self.solve()

@@ -1,0 +1,101 @@
+"""world_size > 1 on CPU (gloo): the 2-D block-cyclic driver (sympgpr_amd/dist.py) with the
+NumPy block backend must reproduce the single-process oracle fit -- distribution logic,
+broadcast / reduce pattern, block bookkeeping, info propagation."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, N, nb, fam, singular, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SYMPGPR_NO_TORCH_PRELOAD"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympgpr_amd.dist import DistFit
+        from tests.ref_ops import RefOps
+        rng = np.random.default_rng(1234)
+        q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+        l = 2.0 * np.sqrt(12 * np.pi / N)
+        hyp = [l, l, 1.0]
+        s2 = 1e-2 / l**2
+        if singular:
+            # sig < 0 flips the sign of K: Ky is indefinite and a pivot turns negative early
+            hyp, s2 = [l, l, -4.0], 2.0 / l**2
+        f = DistFit(RefOps(), fam, q, P, z, hyp, s2, nb=nb)
+        f.build()
+        info = f.factor()
+        if info == 0:
+            a = f.solve().numpy().copy()
+            out[rank] = (0, a, f.nll)
+        else:
+            out[rank] = (info, None, None)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, N, nb, fam="A", singular=False):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), N, nb, fam, singular, out), nprocs=world, join=True)
+    return dict(out)
+
+
+@pytest.mark.parametrize("world,N,nb", [(2, 32, 4), (4, 32, 4), (4, 64, 8), (6, 48, 4), (1, 24, 4)])
+def test_block_cyclic_fit_matches_oracle(oracle, world, N, nb):
+    res = _run(world, N, nb)
+    rng = np.random.default_rng(1234)
+    q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+    l = 2.0 * np.sqrt(12 * np.pi / N)
+    a_o, nll_o, _ = oracle.fit("A", q, P, z, [l, l, 1.0], 1e-2 / l**2)
+    assert len(res) == world
+    for r in range(world):
+        info, a, nll = res[r]
+        assert info == 0
+        assert np.linalg.norm(a - a_o) / np.linalg.norm(a_o) < 1e-11
+        assert nll == pytest.approx(nll_o, rel=1e-11)
+
+
+def test_block_cyclic_family_c(oracle):
+    N, nb = 32, 8
+    res = _run(2, N, nb, fam="C")
+    rng = np.random.default_rng(1234)
+    q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+    l = 2.0 * np.sqrt(12 * np.pi / N)
+    a_o, _, _ = oracle.fit("C", q, P, z, [l, l, 1.0], 1e-2 / l**2)
+    assert np.linalg.norm(res[0][1] - a_o) / np.linalg.norm(a_o) < 1e-11
+
+
+def test_block_cyclic_not_pd_reports_same_info_everywhere():
+    res = _run(4, 32, 4, singular=True)
+    infos = {res[r][0] for r in range(4)}
+    # same LAPACK-style index as dpotrf on the assembled matrix
+    import scipy.linalg
+    from oracle.oracle import Oracle
+    N = 32
+    rng = np.random.default_rng(1234)
+    q, P = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N)
+    l = 2.0 * np.sqrt(12 * np.pi / N)
+    Ky = Oracle().build_K("A", q, P, q, P, [l, l, -4.0]) + 2.0 / l**2 * np.eye(2 * N)
+    expect = scipy.linalg.lapack.dpotrf(Ky, lower=1)[1]
+    assert expect > 0 and infos == {expect}
+
+
+def test_grid_shape():
+    from sympgpr_amd.dist import grid_shape
+    assert [grid_shape(w) for w in (1, 2, 4, 6, 8)] == [(1, 1), (2, 1), (2, 2), (3, 2), (4, 2)]
