@@ -93,7 +93,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--nb", type=int, default=1024, help="block size of the multi-GPU block-cyclic layout")
     ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
-    ap.add_argument("--full-matrix", action="store_true", help="build all of K, not only the lower triangle")
+    ap.add_argument("--lower-only", action="store_true",
+                    help="build only the lower triangle of K (what the factor reads) instead of the "
+                         "full matrix build_K defines")
     args = ap.parse_args()
 
     import torch
@@ -134,7 +136,7 @@ def main():
     n_pts = args.n_pts
     n = 2 * n_pts
     q, P, z, hyp, s2 = synth(n_pts)
-    fit = SympFit(args.family, q, P, z, hyp, s2, lower_only=not args.full_matrix)
+    fit = SympFit(args.family, q, P, z, hyp, s2, lower_only=args.lower_only)
 
     for _ in range(args.warmup):
         fit.run()
@@ -162,7 +164,7 @@ def main():
     nll = fit.nll()
     fit.close()
 
-    gram_bytes = 8.0 * n * (n + 1) / 2 if not args.full_matrix else 8.0 * n * n
+    gram_bytes = 8.0 * n * (n + 1) / 2 if args.lower_only else 8.0 * n * n
     chol_flop = n**3 / 3.0
     out = {
         "metric": METRIC,
@@ -173,7 +175,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "synthetic d=2 N=%d: matrix order n=%d (%.1f GB fp64), family %s, "
                                "l=2*sqrt(12pi/N), sig2n=1e-2/l^2" % (n_pts, n, 8.0 * n * n / 1e9, args.family),
-                   "n_pts": n_pts, "order_n": n, "triangle": "full" if args.full_matrix else "lower"},
+                   "n_pts": n_pts, "order_n": n, "triangle": "lower" if args.lower_only else "full"},
         "gram_gb_s": gram_bytes / (stage[0] * 1e-3) / 1e9,
         "gram_ms": stage[0],
         "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12,

@@ -54,7 +54,8 @@ enum { SGPR_G_QQ = 1, SGPR_G_PQ = 2, SGPR_G_QP = 4, SGPR_G_PP = 8, SGPR_G_ALL = 
 
 /* fit flags */
 enum { SGPR_FIT_LOWER_ONLY = 1,  /* build only the lower triangle (what the factor reads)   */
-       SGPR_FIT_KEEP_K = 2 };    /* keep an untouched copy of Ky next to L (2x memory)       */
+       SGPR_FIT_KEEP_K = 2,      /* keep an untouched copy of Ky next to L (2x memory)       */
+       SGPR_FIT_REG = 4 };       /* scalar-kernel GP (buildKreg, n = n_pts): nll_chol_reg     */
 
 int sgpr_abi_version(void);
 const char *sgpr_last_error(void);
@@ -88,7 +89,8 @@ int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, i
  * replaces python/functions/func.py:189-196 (nll_chol) / :165-171 (gpsolve) on (x, x). */
 typedef struct sgpr_fit *sgpr_fit_t;
 
-/* Allocates HBM for an n = 2*n_pts order system and uploads x, y (n_pts each), z (2*n_pts). */
+/* Allocates HBM for an n = 2*n_pts order system (n = n_pts with SGPR_FIT_REG) and uploads
+ * x, y (n_pts each), z (n). */
 int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, const double *z,
                     const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
                     sgpr_fit_t *out);

@@ -7,7 +7,7 @@ import numpy as np
 FAMILIES = {"A": 0, "B": 1, "C": 2, "D": 3}
 K_KERN, K_DXDX0, K_DYDY0, K_DXDY0 = 0, 1, 2, 3
 G_QQ, G_PQ, G_QP, G_PP, G_ALL, G_LOWER, G_OCML = 1, 2, 4, 8, 15, 16, 32
-FIT_LOWER_ONLY, FIT_KEEP_K = 1, 2
+FIT_LOWER_ONLY, FIT_KEEP_K, FIT_REG = 1, 2, 4
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)

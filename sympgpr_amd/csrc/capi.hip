@@ -234,7 +234,7 @@ int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, con
     if (flags & SGPR_FIT_KEEP_K) { set_error("fit_create: SGPR_FIT_KEEP_K not implemented"); return SGPR_E_ARG; }
     sgpr_fit *f = new (std::nothrow) sgpr_fit;
     if (!f) return SGPR_E_NOMEM;
-    f->family = family; f->npts = n_pts; f->n = 2 * n_pts; f->flags = flags;
+    f->family = family; f->npts = n_pts; f->n = (flags & SGPR_FIT_REG) ? n_pts : 2 * n_pts; f->flags = flags;
     f->st = static_cast<hipStream_t>(stream);
     if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
     f->sig2n = sig2n;
@@ -288,8 +288,13 @@ int sgpr_fit_build(sgpr_fit_t f)
     unsigned flags = SGPR_G_ALL;
     if (f->flags & SGPR_FIT_LOWER_ONLY) flags |= SGPR_G_LOWER;
     SGPR_HIP(hipEventRecord(f->ev[0], f->st));
+    int rc;
+    if (f->flags & SGPR_FIT_REG) {
+        // Ky = buildKreg(x, x) + |sig2n| I  (func.py:182-183)
+        rc = gram_reg(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, n, 0, std::fabs(f->sig2n), f->st);
+    } else
     // Ky = build_K(x, x) + |sig2n| I  (func.py:191-192), noise fused into the diagonal tiles
-    int rc = gram_pairs(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, f->dA + N,
+    rc = gram_pairs(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, f->dA + N,
                         f->dA + n * N, f->dA + N + n * N, n, 0, std::fabs(f->sig2n), flags, f->st);
     if (rc) return rc;
     SGPR_HIP(hipEventRecord(f->ev[1], f->st));
@@ -417,6 +422,11 @@ int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P,
     if ((rc = upload(dq, q, m, f->st)) || (rc = upload(dP, P, m, f->st)) ||
         (rc = dop.alloc(m * sizeof(double))) || (rc = doq.alloc(m * sizeof(double))))
         return rc;
+    SGPR_HIP(hipMemsetAsync(doq.p, 0, m * sizeof(double), f->st));
+    if (f->flags & SGPR_FIT_REG)  // scalar-kernel GP: one row per test point, written to out_p; out_q = 0
+        rc = predict_reg(f->family, m, dq.as<double>(), dP.as<double>(), f->npts, f->dx, f->dy, f->kc,
+                         f->dalpha, dop.as<double>(), f->st);
+    else
     rc = predict_rows(f->family, m, dq.as<double>(), dP.as<double>(), f->npts, f->dx, f->dy, f->kc,
                       f->dalpha, dop.as<double>(), doq.as<double>(), f->st);
     if (rc) return rc;

@@ -11,18 +11,19 @@ from . import _lib as L
 
 
 class SympFit:
-    def __init__(self, family, x, y, z, hyp, sig2n, lower_only=True, stream=None):
+    def __init__(self, family, x, y, z, hyp, sig2n, lower_only=True, stream=None, reg=False):
+        """reg=True: the scalar-kernel GP of buildKreg / nll_chol_reg (order n = len(x))."""
         self._lib = L.load_library()
         self._h = C.c_void_p()
         x, y, hyp = L.f64(x), L.f64(y), L.f64(hyp)
         if x.shape != y.shape or x.ndim != 1:
             raise ValueError("x and y must be 1-D arrays of equal length")
         self.n_pts = len(x)
-        self.n = 2 * self.n_pts
+        self.n = self.n_pts if reg else 2 * self.n_pts
         z = L.f64(z) if z is not None else np.zeros(self.n)
         if z.shape != (self.n,):
-            raise ValueError("z must have length 2*len(x)")
-        flags = L.FIT_LOWER_ONLY if lower_only else 0
+            raise ValueError("z must have length %d" % self.n)
+        flags = (L.FIT_LOWER_ONLY if lower_only else 0) | (L.FIT_REG if reg else 0)
         L.check(self._lib.sgpr_fit_create(L.family_id(family), self.n_pts, L.dptr(x), L.dptr(y), L.dptr(z),
                                           L.dptr(hyp), len(hyp), float(sig2n), flags,
                                           C.c_void_p(stream or 0), C.byref(self._h)), "sgpr_fit_create")

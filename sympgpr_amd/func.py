@@ -1,0 +1,191 @@
+"""Mirror of the reference's GP library python/functions/func.py -- same names, positional
+order, in-place semantics and error behaviour -- with the hot path on the MI355X.
+
+    reference                               here
+    ------------------------------------    -----------------------------------------------
+    sympgpr.build_k / buildkreg (f2py)      sgpr_build_k_host / sgpr_buildkreg_host
+    scipy.linalg.cholesky(lower=True)       sgpr_potrf_host          (LinAlgError if not PD)
+    solve_triangular x 2                    sgpr_potrs_host
+    nll_chol / nll_chol_reg                 one device-resident sgpr_fit_* pass (K stays in HBM)
+    guessP / calcQ / calcP / applymap       K* rows . alpha on the device, alpha cached
+
+Select the kernel family (which kernels*.f90 the reference would have compiled) with
+`set_family("A"|"B"|"C"|"D")`; default "A" (python/05_tokamak/SympGPR/kernels.f90).
+Not mirrored yet: build_dK, build_dKreg, nll_grad, nll_grad_reg.
+"""
+import numpy as np
+
+from . import kernels as _kernels
+from .fit import SympFit
+from .fortran.sympgpr import sympgpr
+from .kernels import *  # noqa: F401,F403  (kern_num, d2kdxdx0_num, ... like `from kernels import *`, func.py:15)
+from .ops import cholesky as _cholesky
+from .ops import get_family, set_family, solve_cholesky as _solve_cholesky  # noqa: F401
+from .predict import Predictor, solve_implicit_P
+
+
+def _l(l):
+    return tuple(float(v) for v in l)
+
+
+def f_kern(x, y, x0, y0, l):            # functions/func.py:17-18
+    return _kernels.kern_num(x, y, x0, y0, *_l(l))
+
+
+def d2kdxdx0(x, y, x0, y0, l):          # :20-21
+    return _kernels.d2kdxdx0_num(x, y, x0, y0, *_l(l))
+
+
+def d2kdydy0(x, y, x0, y0, l):          # :23-24
+    return _kernels.d2kdydy0_num(x, y, x0, y0, *_l(l))
+
+
+def d2kdxdy0(x, y, x0, y0, l):          # :26-27
+    return _kernels.d2kdxdy0_num(x, y, x0, y0, *_l(l))
+
+
+def d2kdydx0(x, y, x0, y0, l):          # :29-30
+    return d2kdxdy0(x, y, x0, y0, l)
+
+
+def build_K(xin, x0in, hyp, K):
+    """functions/func.py:32-40: covariance with derivative observations, Eq. (38); K in place."""
+    N = K.shape[0] // 2
+    N0 = K.shape[1] // 2
+    x0 = x0in[0:N0]
+    x = xin[0:N]
+    y0 = x0in[N0:2 * N0]
+    y = xin[N:2 * N]
+    sympgpr.build_k(x, y, x0, y0, hyp, K)
+
+
+def buildKreg(xin, x0in, hyp, K):
+    """functions/func.py:42-50: scalar-kernel covariance on the regular (q,p) grid; K in place."""
+    N = K.shape[0]
+    N0 = K.shape[1]
+    x0 = x0in[0:N0]
+    x = xin[0:N]
+    y0 = x0in[N0:2 * N0]
+    y = xin[N:2 * N]
+    sympgpr.buildkreg(x, y, x0, y0, hyp, K)
+
+
+def gpsolve(Ky, ft):
+    """functions/func.py:165-171 -> (L, alpha)."""
+    Lf = _cholesky(Ky, lower=True)
+    return Lf, _solve_cholesky(Lf, ft)
+
+
+def solve_cholesky(L, b):
+    """functions/func.py:174-177."""
+    return _solve_cholesky(L, b)
+
+
+def nll_chol_reg(hyp, x, y, N):
+    """functions/func.py:180-187: negative log-posterior of the scalar-kernel GP.  N = matrix
+    order; x holds (q || p) and is sliced exactly as buildKreg does."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    with SympFit(get_family(), x[0:N], x[N:2 * N], np.asarray(y, dtype=np.float64)[:N], hyp[:-1],
+                 np.abs(hyp[-1]), reg=True) as f:
+        return f.run().nll()
+
+
+def nll_chol(hyp, x, y, N):
+    """functions/func.py:189-196: negative log-posterior of the symplectic GP.  N = matrix order
+    (twice the number of points build_K slices out of x)."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    npts = N // 2
+    with SympFit(get_family(), x[0:npts], x[npts:2 * npts], np.asarray(y, dtype=np.float64)[:2 * npts],
+                 hyp[:-1], np.abs(hyp[-1])) as f:
+        return f.run().nll()
+
+
+def guessP(x, y, hypp, xtrainp, ztrainp, Kyinvp):
+    """functions/func.py:198-201."""
+    Ntrain = len(xtrainp) // 2
+    return sympgpr.guessp(x, y, hypp, xtrainp[0:Ntrain], xtrainp[Ntrain:], ztrainp, Kyinvp)
+
+
+def calcQ(x, y, xtrain, l, Kyinv, ztrain):
+    """functions/func.py:204-207."""
+    Ntrain = len(xtrain) // 2
+    return sympgpr.calcq(x, y, xtrain[:Ntrain], xtrain[Ntrain:], l, Kyinv, ztrain)
+
+
+def calcP(x, y, l, hypp, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv):
+    """functions/func.py:209-213."""
+    Ntrain = len(xtrain) // 2
+    Ntrainp = len(xtrainp) // 2
+    return sympgpr.calcp(x, y, l, hypp, xtrainp[:Ntrainp], xtrainp[Ntrainp:], ztrainp, Kyinvp,
+                         xtrain[:Ntrain], xtrain[Ntrain:], ztrain, Kyinv)
+
+
+def _applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv, wrap):
+    """Same recurrences as the reference's double loop (functions/func.py:216-237), with the
+    Ntest orbits of a time step evaluated as one device batch and alpha = Kyinv ztrain formed
+    once instead of inside every calcP / calcQ call."""
+    Ntrain, Ntrainp = len(xtrain) // 2, len(xtrainp) // 2
+    fam = get_family()
+    pred = Predictor(fam, xtrain[:Ntrain], xtrain[Ntrain:], l, np.asarray(Kyinv) @ np.asarray(ztrain))
+    predp = Predictor(fam, xtrainp[:Ntrainp], xtrainp[Ntrainp:], hypp, np.asarray(Kyinvp) @ np.asarray(ztrainp),
+                      reg=True)
+    pmap = np.zeros([nm, Ntest])
+    qmap = np.zeros([nm, Ntest])
+    pmap[0, :] = P0map
+    qmap[0, :] = Q0map
+    for i in range(0, nm - 1):
+        ok = ~np.isnan(pmap[i, :]) & ~np.isnan(qmap[i, :])
+        pmap[i + 1, :] = np.nan
+        qmap[i + 1, :] = np.nan
+        if not ok.any():
+            continue
+        # new P including Newton for the implicit Eq. (42), then Q from Eq. (43)
+        Pn = solve_implicit_P(pred, predp, qmap[i, ok], pmap[i, ok])
+        pmap[i + 1, ok] = Pn
+        good = ok.copy()
+        good[ok] = ~np.isnan(Pn)
+        if good.any():
+            dq = pred(qmap[i, good], pmap[i + 1, good])[1]
+            qn = dq + qmap[i, good]
+            qmap[i + 1, good] = np.mod(qn, 2.0 * np.pi) if wrap else qn
+    return qmap, pmap
+
+
+def applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv):
+    """functions/func.py:216-237 (q taken mod 2 pi)."""
+    return _applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv, True)
+
+
+def applymap_henon(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv):
+    """functions/func.py:239-260 (no wrap of q)."""
+    return _applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv, False)
+
+
+def quality(qmap, pmap, H, ysint, Ntest, Nm):
+    """functions/func.py:262-272: geometric distance and energy oscillation (host arithmetic,
+    not part of the accelerated path)."""
+    gd = np.zeros([Ntest])
+    for lk in range(0, Ntest):
+        d = np.array([qmap[1, lk], pmap[1, lk]]) - np.asarray(ysint)[Nm, :, lk]
+        gd[lk] = np.mean(d * d)          # sklearn.metrics.mean_squared_error of two 2-vectors
+    stdgd = np.std(gd[:])
+    Eosc = np.zeros([Ntest])
+    for lk in range(0, Ntest):
+        Eosc[lk] = np.std(H[:, lk]) / np.mean(H[:, lk])
+    return Eosc, gd, stdgd
+
+
+def _not_yet(name):
+    def f(*a, **k):
+        raise NotImplementedError(name + " is not part of the accelerated path yet (SURVEY.md 8(f) rank 2: "
+                                  "hyper-parameter gradients need the third-derivative kernels on the device)")
+    f.__name__ = name
+    return f
+
+
+build_dKreg = _not_yet("build_dKreg")
+build_dK = _not_yet("build_dK")
+nll_grad_reg = _not_yet("nll_grad_reg")
+nll_grad = _not_yet("nll_grad")

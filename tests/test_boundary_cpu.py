@@ -1,0 +1,130 @@
+"""CPU suite for the boundary: libsympgpr_hip.so loads, exports every symbol the header declares,
+the ctypes table matches the header, the Python mirror has the reference's call surface, and
+compute calls FAIL LOUDLY without a GPU (no CPU fallback)."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sympgpr_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgpr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from sympgpr_amd import _lib
+    lib = ctypes.CDLL(_lib.lib_path())
+    syms = _header_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(lib, s), "libsympgpr_hip.so does not export " + s
+
+
+def test_ctypes_table_matches_header():
+    from sympgpr_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _header_symbols()
+    lib = _lib.load_library()
+    assert lib.sgpr_abi_version() == 1
+
+
+def test_mirror_has_reference_call_surface():
+    """names and positional parameters of python/functions/func.py."""
+    from sympgpr_amd import func
+    expect = {
+        "f_kern": ["x", "y", "x0", "y0", "l"], "d2kdxdx0": ["x", "y", "x0", "y0", "l"],
+        "d2kdydy0": ["x", "y", "x0", "y0", "l"], "d2kdxdy0": ["x", "y", "x0", "y0", "l"],
+        "d2kdydx0": ["x", "y", "x0", "y0", "l"],
+        "build_K": ["xin", "x0in", "hyp", "K"], "buildKreg": ["xin", "x0in", "hyp", "K"],
+        "gpsolve": ["Ky", "ft"], "solve_cholesky": ["L", "b"],
+        "nll_chol_reg": ["hyp", "x", "y", "N"], "nll_chol": ["hyp", "x", "y", "N"],
+        "guessP": ["x", "y", "hypp", "xtrainp", "ztrainp", "Kyinvp"],
+        "calcQ": ["x", "y", "xtrain", "l", "Kyinv", "ztrain"],
+        "calcP": ["x", "y", "l", "hypp", "xtrainp", "ztrainp", "Kyinvp", "xtrain", "ztrain", "Kyinv"],
+        "applymap": ["nm", "Ntest", "l", "hypp", "Q0map", "P0map", "xtrainp", "ztrainp", "Kyinvp", "xtrain",
+                     "ztrain", "Kyinv"],
+        "applymap_henon": ["nm", "Ntest", "l", "hypp", "Q0map", "P0map", "xtrainp", "ztrainp", "Kyinvp", "xtrain",
+                           "ztrain", "Kyinv"],
+        "quality": ["qmap", "pmap", "H", "ysint", "Ntest", "Nm"],
+    }
+    for name, params in expect.items():
+        assert list(inspect.signature(getattr(func, name)).parameters) == params, name
+    for name in ("kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num", "build_dK", "build_dKreg",
+                 "nll_grad", "nll_grad_reg"):
+        assert hasattr(func, name)
+    from sympgpr_amd.fortran.sympgpr import sympgpr
+    for name in ("build_k", "buildkreg", "guessp", "calcq", "calcp", "applymap_tok"):
+        assert callable(getattr(sympgpr, name))
+
+
+def test_dropin_modules_resolve(monkeypatch):
+    import importlib
+    import sys
+    monkeypatch.syspath_prepend(os.path.join(ROOT, "sympgpr_amd", "dropin"))
+    for m in ("func", "kernels", "fortran", "fortran.sympgpr"):
+        sys.modules.pop(m, None)
+    func = importlib.import_module("func")
+    kernels = importlib.import_module("kernels")
+    sp = importlib.import_module("fortran.sympgpr")
+    assert func.build_K and kernels.kern_num and sp.sympgpr.build_k
+    for m in ("func", "kernels", "fortran", "fortran.sympgpr"):
+        sys.modules.pop(m, None)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import sympgpr_amd
+    from sympgpr_amd import ops
+    from sympgpr_amd.fit import SympFit
+    if sympgpr_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    K = np.empty((4, 4), order="F")
+    with pytest.raises(sympgpr_amd.NoDeviceError):
+        ops.build_k([1.0, 2.0], [0.0, 1.0], [1.0, 2.0], [0.0, 1.0], [0.5, 2.0, 0.4], K)
+    with pytest.raises(sympgpr_amd.NoDeviceError):
+        ops.cholesky(np.eye(3))
+    with pytest.raises(sympgpr_amd.NoDeviceError):
+        SympFit("A", [1.0, 2.0], [0.0, 1.0], np.zeros(4), [0.5, 2.0, 0.4], 1e-3)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sympgpr_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f)).read()
+                assert "oracle" not in txt.replace("oracle/", "").lower() or f in ("__init__.py",) or \
+                    "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_host_math_matches_libm():
+    """devmath.h (the in-house exp / sincos of the Gram kernels) compiled for the host with g++:
+    exp <= 1 ulp-ish relative, sin/cos <= 1.5e-16 absolute on the arguments the kernels see."""
+    import subprocess
+    import tempfile
+    src = r'''
+#define SGPR_HOST_MATH_TEST
+#include "devmath.h"
+#include <cstdio>
+#include <random>
+int main(){ std::mt19937_64 g(1); std::uniform_real_distribution<double> ux(-745,1), uh(-1e4,1e4), us(-7,7);
+ double me=0, ms=0, mc=0;
+ for(int i=0;i<400000;i++){ double x=ux(g); if(i%2) x=-std::exp(us(g));
+  double e=sgpr::exp_fast(x), r=std::exp(x); double d=std::fabs(e-r)/r; if(r>1e-300 && d>me) me=d;
+  double h=(i%3)?us(g):uh(g); double s,c; sgpr::sincos_fast(h,s,c);
+  long double sl=sinl((long double)h), cl=cosl((long double)h);
+  double ds=std::fabs((double)(s-sl)), dc=std::fabs((double)(c-cl)); if(ds>ms)ms=ds; if(dc>mc)mc=dc; }
+ printf("%.3e %.3e %.3e\n",me,ms,mc); }
+'''
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.cpp"), "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run(["g++", "-O2", "-mfma", "-I", os.path.join(ROOT, "sympgpr_amd", "csrc"),
+                        os.path.join(td, "t.cpp"), "-o", exe], check=True)
+        me, ms, mc = map(float, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
+    assert me < 4e-16 and ms < 1.5e-16 and mc < 1.5e-16

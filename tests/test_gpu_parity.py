@@ -353,3 +353,103 @@ def test_block_cyclic_hip_ops(oracle, world, backend, N, nb):
         a, nll = out[r]
         assert np.linalg.norm(a - a_ref) / np.linalg.norm(a_ref) < 1e-10
         assert nll == pytest.approx(nll_ref, rel=1e-11)
+
+
+# ---------------------------------------------------------------- the func.py mirror
+def test_mirror_reference_equivalence_checks(ka):
+    """The reference's own test (05_tokamak/SympGPR/test_sympgpr.py:19-75) asserts
+    func.py == Fortran to 1e-12 for buildKreg, build_K, guessP, calcQ, calcP on fixed inputs;
+    the mirror is held to the values the reference's Fortran returns for them."""
+    from sympgpr_amd import func
+    from sympgpr_amd.fortran.sympgpr import sympgpr
+    func.set_family("A")
+    x, y, x0, y0 = (np.array(ka[k]) for k in ("x", "y", "x0", "y0"))
+    hyp, hypp = np.array(ka["hyp"]), np.array(ka["hypp"])
+    N, N0 = 3, 2
+    K = np.empty([N, N0], order="F")
+    func.buildKreg(np.hstack((x, y)), np.hstack((x0, y0)), hyp, K)
+    Kf = np.empty([N, N0], order="F")
+    sympgpr.buildkreg(x, y, x0, y0, hyp, Kf)
+    assert np.allclose(K, Kf, rtol=1e-12, atol=1e-12)
+    assert np.allclose(K, np.array(ka["buildKreg_3x2"]), rtol=1e-12, atol=1e-12)
+    K = np.empty([2 * N, 2 * N0], order="F")
+    func.build_K(np.hstack((x, y)), np.hstack((x0, y0)), hyp, K)
+    assert np.allclose(K, np.array(ka["build_K_6x4"]), rtol=1e-12, atol=1e-12)
+    Kyinvp = np.array(ka["Kyinvp"], order="F"); ztrainp = np.array(ka["ztrainp"])
+    Kyinv = np.array(ka["Kyinv"], order="F"); ztrain = np.array(ka["ztrain"])
+    pg = func.guessP(x[0], y[0], hypp, np.hstack((x0, y0)), ztrainp, Kyinvp)
+    assert np.allclose(pg, ka["guessP"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(sympgpr.guessp(x[0], y[0], hypp, x0, y0, ztrainp, Kyinvp), ka["guessP"], rtol=1e-12, atol=1e-12)
+    qq = func.calcQ(x[0], y[0], np.hstack((x0, y0)), hyp, Kyinv, ztrain)
+    assert np.allclose(qq, ka["calcQ"], rtol=1e-12, atol=1e-12)
+    pp = func.calcP(x[0], y[0], hyp, hypp, np.hstack((x0, y0)), ztrainp, Kyinvp, np.hstack((x0, y0)), ztrain, Kyinv)
+    # hybrd1 stops at tol 1e-13 (sympgpr.f90:107); the secant root agrees far inside 1e-10
+    assert np.allclose(pp, ka["calcP"], rtol=1e-10, atol=1e-10)
+    # scalar kernel wrappers
+    assert func.f_kern(x0[0], y0[0], x[1], y[1], hyp[:2]) * hyp[2] == pytest.approx(ka["buildKreg_3x2"][1][0], rel=1e-13)
+    assert func.d2kdydx0(1.0, 0.0, 2.0, 3.0, hyp[:2]) == func.d2kdxdy0(1.0, 0.0, 2.0, 3.0, hyp[:2])
+
+
+def test_mirror_gpsolve_nll(fits, oracle):
+    from sympgpr_amd import func
+    func.set_family("A")
+    g = lambda k: fits[f"A_N128_{k}"]
+    N = 256
+    x = np.hstack((g("q"), g("P")))
+    hyp4 = np.append(g("hyp"), -float(g("sig2n")))  # nll_chol takes abs(hyp[-1]) (func.py:192)
+    assert func.nll_chol(hyp4, x, g("z"), N) == pytest.approx(float(g("nll")), rel=1e-11)
+    K = np.empty((N, N), order="F")
+    func.build_K(x, x, g("hyp"), K)
+    Ky = K + float(g("sig2n")) * np.eye(N)
+    Lf, alpha = func.gpsolve(Ky, g("z"))
+    assert np.linalg.norm(alpha - g("alpha")) / np.linalg.norm(g("alpha")) < 1e-10
+    assert np.all(np.triu(Lf, 1) == 0)
+    np.testing.assert_allclose(func.solve_cholesky(Lf, g("z")), alpha, rtol=0, atol=0)
+    # SURVEY 3.5 quirk: the regular GP tuned with the symplectic nll on an N x N matrix whose
+    # build_K slices N/2 "points" out of a longer x
+    assert func.nll_chol(hyp4, x, g("z")[:128], 128) == pytest.approx(
+        oracle.fit("A", x[:64], x[64:128], g("z")[:128], g("hyp"), float(g("sig2n")))[1], rel=1e-11)
+    # scalar-kernel GP
+    Kr = oracle.buildKreg("A", g("q"), g("P"), g("q"), g("P"), g("hyp")) + float(g("sig2n")) * np.eye(128)
+    Lr = oracle.cholesky(Kr)
+    ar = oracle.solve_cholesky(Lr, g("z")[:128])
+    assert func.nll_chol_reg(hyp4, x, g("z")[:128], 128) == pytest.approx(oracle.nll(Lr, g("z")[:128], ar), rel=1e-11)
+
+
+def test_mirror_applymap_vs_pointwise_reference(oracle):
+    """applymap (functions/func.py:216-237) against the reference recurrences written out with
+    the oracle's K*-rows and MINPACK hybrd (scipy.optimize.fsolve, the solver behind hybrd1)."""
+    import scipy.optimize
+    from sympgpr_amd import func
+    func.set_family("A")
+    rng = np.random.default_rng(11)
+    Nt = 40
+    q, P = rng.uniform(0, 2 * np.pi, Nt), rng.uniform(-1, 1, Nt)
+    # a gentle symplectic map as training data: Q = q + 0.3 P', P' = p - 0.3 sin q
+    pn = P; p_old = pn + 0.3 * np.sin(q); Q = q + 0.3 * pn
+    xtrain = np.hstack((q, pn)); ztrain = np.hstack((p_old - pn, Q - q))
+    xtrainp = np.hstack((q, p_old)); ztrainp = pn
+    hyp = np.array([1.2, 1.5, 1.0]); hypp = np.array([1.2, 1.5, 1.0])
+    K = oracle.build_K("A", q, pn, q, pn, hyp) + 1e-8 * np.eye(2 * Nt)
+    Kp = oracle.buildKreg("A", q, p_old, q, p_old, hypp) + 1e-8 * np.eye(Nt)
+    Kyinv, Kyinvp = np.linalg.inv(K), np.linalg.inv(Kp)
+    Ntest, nm = 5, 6
+    Q0, P0 = rng.uniform(0.5, 5.5, Ntest), rng.uniform(-0.5, 0.5, Ntest)
+    qmap, pmap = func.applymap(nm, Ntest, hyp, hypp, Q0, P0, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv)
+    alpha, alphap = Kyinv @ ztrain, Kyinvp @ ztrainp
+    qr, pr = np.zeros((nm, Ntest)), np.zeros((nm, Ntest))
+    qr[0], pr[0] = Q0, P0
+    for i in range(nm - 1):
+        for k in range(Ntest):
+            g0 = oracle.predict_reg("A", [qr[i, k]], [pr[i, k]], q, p_old, hypp, alphap)[0]
+            f = lambda Pn: oracle.predict_rows("A", [qr[i, k]], [Pn[0]], q, pn, hyp, alpha)[0][0] - pr[i, k] + Pn[0]
+            pr[i + 1, k] = scipy.optimize.fsolve(f, [g0], xtol=1e-13)[0]
+            dq = oracle.predict_rows("A", [qr[i, k]], [pr[i + 1, k]], q, pn, hyp, alpha)[1][0]
+            qr[i + 1, k] = np.mod(dq + qr[i, k], 2 * np.pi)
+    np.testing.assert_allclose(pmap, pr, rtol=1e-8, atol=1e-8)   # the reference's applymap tolerance (test_sympgpr.py:92-93)
+    np.testing.assert_allclose(qmap, qr, rtol=1e-8, atol=1e-8)
+    # NaN start = lost orbit stays lost, the others are unaffected (functions/func.py:231-232)
+    P0n = P0.copy(); P0n[2] = np.nan
+    q2, p2 = func.applymap(3, Ntest, hyp, hypp, Q0, P0n, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv)
+    assert np.all(np.isnan(p2[1:, 2])) and np.all(np.isnan(q2[1:, 2]))
+    np.testing.assert_allclose(np.delete(p2, 2, axis=1), np.delete(pmap[:3], 2, axis=1), rtol=1e-12)
