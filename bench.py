@@ -90,9 +90,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2N)")
     ap.add_argument("--family", default="A")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="N of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--nb", type=int, default=1024, help="block size of the multi-GPU block-cyclic layout")
     ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
+    ap.add_argument("--no-launch-events", action="store_true",
+                    help="skip the per-launch HIP-event timing of the GEMM kernel (use under rocprofv3 --pmc)")
     ap.add_argument("--lower-only", action="store_true",
                     help="build only the lower triangle of K (what the factor reads) instead of the "
                          "full matrix build_K defines")
@@ -143,7 +145,8 @@ def main():
     stage = np.zeros(3)
     prof = np.zeros(8)
     barrier()
-    L.check(lib.sgpr_profile_begin())
+    if not args.no_launch_events:
+        L.check(lib.sgpr_profile_begin())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fit.run()
@@ -184,18 +187,29 @@ def main():
         "residual_Ky_alpha_minus_z": resid,
         "nll": nll,
     }
+    # HBM-side traffic per launch comes from the committed PMC passes of this same configuration
+    # (rocprofv3 --pmc crashes when combined with the per-launch HIP events used here, so it is a
+    # separate run: profiles/r01/pmc_traffic_n131072.json); null for any other configuration.
+    traffic = {}
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_n131072.json")))
+        if pm["config"]["n_pts"] == n_pts and pm["config"]["family"] == args.family and not args.lower_only:
+            traffic = {"gemm": pm["gemm_nt_kernel<256, 128>"]["traffic_bytes_per_launch"],
+                       "gram": pm["gram_pairs_kernel"]["traffic_bytes_per_launch"]}
+    except Exception:
+        pass
     big_n, big_flop, big_ms = prof[0], prof[1], prof[2]
     if big_n > 0 and big_ms > 0:
         ach = big_flop / (big_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (fp64 MFMA trailing update)",
                            "achieved": ach, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
-                           "frac": ach / MFMA_F64_PEAK_TF, "traffic": None,
+                           "frac": ach / MFMA_F64_PEAK_TF, "traffic": traffic.get("gemm"),
                            "launches": int(big_n), "flop_per_launch": big_flop / big_n,
                            "avg_launch_ms": big_ms / big_n,
                            "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}
     out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel", "achieved": out["gram_gb_s"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["gram_gb_s"] / HBM_PEAK_GBS,
-                            "traffic": None}
+                            "traffic": traffic.get("gram")}
     if args.cpu_sample > 0:
         cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family, args.cpu_sample)
         with SympFit(args.family, qs, Ps, zs, hs, s2s) as fs:
