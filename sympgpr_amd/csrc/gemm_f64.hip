@@ -69,7 +69,10 @@ struct GemmArgs {
 // speed-only assumption: any other placement computes the same tiles.
 // `tri`: square SYRK with the diagonal at 0 -- only super-tiles touching the lower triangle are
 // enumerated (column-major over super-columns), so no workgroup slot is spent on an early exit.
-constexpr int SR = 8, SC = 4;
+// The super-tile is SR x SC tiles with SR*BM == 4*SC*BN (2048 x 512 of C for the 256x128 shape,
+// 1024 x 256 for the 128x128 shape), which is what the triangular closed form assumes.
+constexpr int SR = 8;
+template <int SC>
 __device__ __forceinline__ bool tile_of(const GemmArgs &g, int &tile_r, int &tile_c)
 {
     const int L = blockIdx.x;
@@ -374,19 +377,23 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
         offB[j] = kc * LDB_S + seg * 128;
     }
     const size_t stepA = (size_t)BK * g.lda, stepB = (size_t)BK * g.ldb;
-    auto dma = [&](int t, int buf) {
-        double *dA = sA0 + buf * BK * LDA_S, *dB = sB0 + buf * BK * LDB_S;
-#pragma unroll
-        for (int j = 0; j < QA; ++j)
+    // one LDS-DMA instruction: q < QA -> A piece q, else B piece q - QA
+    auto dma_one = [&](int t, int buf, int q) {
+        if (q < QA) {
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(srcA[j] + (size_t)t * stepA),
-                (__attribute__((address_space(3))) void *)(dA + offA[j]), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < QB; ++j)
+                (const __attribute__((address_space(1))) void *)(srcA[q] + (size_t)t * stepA),
+                (__attribute__((address_space(3))) void *)(sA0 + buf * BK * LDA_S + offA[q]), 16, 0, 0);
+        } else {
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(srcB[j] + (size_t)t * stepB),
-                (__attribute__((address_space(3))) void *)(dB + offB[j]), 16, 0, 0);
+                (const __attribute__((address_space(1))) void *)(srcB[q - QA] + (size_t)t * stepB),
+                (__attribute__((address_space(3))) void *)(sB0 + buf * BK * LDB_S + offB[q - QA]), 16, 0, 0);
+        }
     };
+    auto dma = [&](int t, int buf) {
+#pragma unroll
+        for (int q = 0; q < QA + QB; ++q) dma_one(t, buf, q);
+    };
+    constexpr int NQ = QA + QB;
 
     double fa0[4], fb0[4], fa1[4], fb1[4];
     auto mfma_rows = [&](const double (&fa)[4], const double (&fb)[4], int i0, int i1) {
@@ -409,18 +416,30 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
         const int cur = t & 1;
         const bool more = (t + 1 < T) && !(g.dbg & 1);
         const unsigned aA = baseA + cur * (BK * LDA_S * 8), aB = baseB + cur * (BK * LDB_S * 8);
-        if (more) dma(t + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // kk = 0
+        // kk = 0 and 1: the copy of tile t+1 goes out one LDS-DMA instruction per MFMA row, so the
+        // matrix pipe never waits behind a burst of address arithmetic + DMA issue
         read_frags<1, LDA_S, LDB_S>(aA, aB, fa1, fb1);
         SGPR_LGKM_WAIT(8);
-        mfma_rows(fa0, fb0, 0, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        // kk = 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mfma_rows(fa0, fb0, i, i + 1);
+            if (more) {
+#pragma unroll
+                for (int q = i * NQ / 8; q < (i + 1) * NQ / 8; ++q) dma_one(t + 1, cur ^ 1, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         read_frags<2, LDA_S, LDB_S>(aA, aB, fa0, fb0);
         SGPR_LGKM_WAIT(8);
-        mfma_rows(fa1, fb1, 0, 4);
-        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mfma_rows(fa1, fb1, i, i + 1);
+            if (more) {
+#pragma unroll
+                for (int q = (4 + i) * NQ / 8; q < (5 + i) * NQ / 8; ++q) dma_one(t + 1, cur ^ 1, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // kk = 2
         read_frags<3, LDA_S, LDB_S>(aA, aB, fa1, fb1);
         SGPR_LGKM_WAIT(8);
@@ -476,7 +495,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_nt_kernel(
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
     __shared__ double smem[2 * BK * (LDA_S + LDB_S)];
     int tile_r, tile_c;
-    if (!tile_of(g, tile_r, tile_c)) return;
+    if (!tile_of<(SR * BM) / (4 * BN)>(g, tile_r, tile_c)) return;
     const int row0 = tile_r * BM, col0 = tile_c * BN;
     if (g.lower) {
         const long rb = ((long)min(row0 + BM, g.m) - 1) / g.lblk, cb = (long)col0 / g.lblk;
@@ -518,10 +537,10 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
     auto set_map = [&](int bm, int bn) {
         g.tiles_m = (m + bm - 1) / bm;
         g.tiles_n = (n + bn - 1) / bn;
+        const int SC = (SR * bm) / (4 * bn);  // 4 for 256x128, 2 for 128x128
         g.n_sr = (g.tiles_m + SR - 1) / SR;
         g.n_sc = (g.tiles_n + SC - 1) / SC;
-        // triangular enumeration needs SR*bm == 4*SC*bn (4 super-columns per super-row)
-        g.tri = (lower && diag_off == 0 && m == n && SR * bm == 4 * SC * bn) ? 1 : 0;
+        g.tri = (lower && diag_off == 0 && m == n) ? 1 : 0;
         if (g.tri) {
             long cnt = 0;
             for (int sc = 0; sc < g.n_sc; ++sc) cnt += g.n_sr - (sc / 4 < g.n_sr ? sc / 4 : g.n_sr);
@@ -532,6 +551,7 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
         if (!g.tri) g.n_super = g.n_sr * g.n_sc;
         return (unsigned)(((g.n_super + 7) / 8) * 8 * SR * SC);
     };
+    (void)0;
     ProfRec rec{};
     if (g_prof.on) {
         // algorithmic flop of this launch: 2k per updated element (lower: on/below the diagonal)

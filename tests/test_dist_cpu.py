@@ -56,7 +56,7 @@ def _run(world, N, nb, fam="A", singular=False):
     return dict(out)
 
 
-@pytest.mark.parametrize("world,N,nb", [(2, 32, 4), (4, 32, 4), (4, 64, 8), (6, 48, 4), (1, 24, 4)])
+@pytest.mark.parametrize("world,N,nb", [(2, 32, 4), (4, 32, 4), (4, 64, 8), (6, 48, 4), (1, 24, 4), (8, 64, 4)])
 def test_block_cyclic_fit_matches_oracle(oracle, world, N, nb):
     res = _run(world, N, nb)
     rng = np.random.default_rng(1234)
