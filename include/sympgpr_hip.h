@@ -50,7 +50,9 @@ enum { SGPR_E_ARG = -1, SGPR_E_NODEVICE = -2, SGPR_E_HIP = -3, SGPR_E_NOMEM = -4
 /* Gram-build part selection / options (sgpr_gram_pairs_dev `flags`) */
 enum { SGPR_G_QQ = 1, SGPR_G_PQ = 2, SGPR_G_QP = 4, SGPR_G_PP = 8, SGPR_G_ALL = 15,
        SGPR_G_LOWER = 16,     /* write qq / PP tiles only where they touch row >= col; skip qP */
-       SGPR_G_OCML = 32 };    /* use the ROCm device-libs exp/sincos instead of the in-house ones */
+       SGPR_G_OCML = 32,      /* use the ROCm device-libs exp/sincos instead of the in-house ones */
+       SGPR_G_DLX = 64,       /* entries of dK/dlx instead of K (build_dK, functions/func.py:80-129) */
+       SGPR_G_DLY = 128 };    /* entries of dK/dly                                                  */
 
 /* fit flags */
 enum { SGPR_FIT_LOWER_ONLY = 1,  /* build only the lower triangle (what the factor reads)   */
@@ -80,6 +82,15 @@ int sgpr_buildkreg_host(int family, int n, int n0, const double *x, const double
 int sgpr_kernel_eval_host(int family, int which, int m, const double *xa, const double *ya,
                           const double *xb, const double *yb, const double *l, int nl,
                           double *out);
+/* build_dK(xin, x0in, hyp)[which] (functions/func.py:80-129; which = 0: d/dlx, 1: d/dly):
+ * dK is (2 n0 x 2 n), rows index the "0" points.  Families A, C, D. */
+int sgpr_build_dk_host(int family, int which, int n, int n0, const double *x, const double *y,
+                       const double *x0, const double *y0, const double *hyp, int nhyp, double *dK,
+                       size_t ld);
+/* build_dKreg(xin, x0in, hyp)[which] (functions/func.py:52-78): dK is (n x n0) */
+int sgpr_build_dkreg_host(int family, int which, int n, int n0, const double *x, const double *y,
+                          const double *x0, const double *y0, const double *hyp, int nhyp, double *dK,
+                          size_t ld);
 /* scipy.linalg.cholesky(A, lower=True) (func.py:166): in place, strict upper zeroed. */
 int sgpr_potrf_host(int n, double *A, size_t lda);
 /* solve_cholesky(L, B) (func.py:174-177): B (n x nrhs) overwritten by L^-T L^-1 B. */
@@ -115,6 +126,9 @@ int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs);
  * out_p[k] = Kstar(1,:).alpha, out_q[k] = Kstar(2,:).alpha */
 int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P, double *out_p,
                           double *out_q);
+/* gradient of the nll with respect to (lx, ly) on a solved fit: what nll_grad / nll_grad_reg
+ * return as nlp_grad (functions/func.py:132-162) */
+int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2);
 /* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
 int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms);
 /* device pointers of the fit (for callers that own a torch / HIP context): K/L, alpha */

@@ -49,6 +49,11 @@ class Oracle:
         for f in (L.orc_build_k, L.orc_buildkreg):
             f.restype = C.c_int
             f.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t, C.c_int]
+        L.orc_scalar_dl.restype = C.c_double
+        L.orc_scalar_dl.argtypes = [C.c_int, C.c_int] + [C.c_double] * 6
+        for f in (L.orc_build_dk, L.orc_build_dkreg):
+            f.restype = C.c_int
+            f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t]
         L.orc_cholesky_lower.restype = C.c_int
         L.orc_cholesky_lower.argtypes = [C.c_int, _dp, C.c_size_t]
         L.orc_solve_cholesky.restype = None
@@ -80,6 +85,51 @@ class Oracle:
         self.lib.orc_buildkreg(FAMILIES[fam], n, n0, _p(x), _p(y), _p(x0), _p(y0), _p(hyp), _p(K),
                                max(n, 1), threads)
         return K
+
+    def scalar_dl(self, fam, which, xa, ya, xb, yb, lx, ly):
+        return self.lib.orc_scalar_dl(FAMILIES[fam], which, xa, ya, xb, yb, lx, ly)
+
+    def build_dK(self, fam, x, y, x0, y0, hyp):
+        """-> [dK/dlx, dK/dly], each (2 n0 x 2 n)  (functions/func.py:80-129)"""
+        x, y, x0, y0, hyp = map(_f64, (x, y, x0, y0, hyp))
+        n, n0 = len(x), len(x0)
+        out = []
+        for w in (0, 1):
+            D = np.empty((2 * n0, 2 * n), order="F")
+            self.lib.orc_build_dk(FAMILIES[fam], w, n, n0, _p(x), _p(y), _p(x0), _p(y0), _p(hyp), _p(D),
+                                  max(2 * n0, 1))
+            out.append(D)
+        return out
+
+    def build_dKreg(self, fam, x, y, x0, y0, hyp):
+        """-> [dK/dlx, dK/dly], each (n x n0)  (functions/func.py:52-78)"""
+        x, y, x0, y0, hyp = map(_f64, (x, y, x0, y0, hyp))
+        n, n0 = len(x), len(x0)
+        out = []
+        for w in (0, 1):
+            D = np.empty((n, n0), order="F")
+            self.lib.orc_build_dkreg(FAMILIES[fam], w, n, n0, _p(x), _p(y), _p(x0), _p(y0), _p(hyp), _p(D),
+                                     max(n, 1))
+            out.append(D)
+        return out
+
+    def nll_grad(self, fam, hyp, x, y, N, reg=False):
+        """functions/func.py:132-162 restated: explicit inverse, slogdet, trace terms."""
+        hyp = np.asarray(hyp, dtype=np.float64)
+        x = np.asarray(x, dtype=np.float64)
+        if reg:
+            K = self.buildKreg(fam, x[:N], x[N:2 * N], x[:N], x[N:2 * N], hyp[:-1])
+            dK = self.build_dKreg(fam, x[:N], x[N:2 * N], x[:N], x[N:2 * N], hyp[:-1])
+        else:
+            h = N // 2
+            K = self.build_K(fam, x[:h], x[h:N], x[:h], x[h:N], hyp[:-1])
+            dK = self.build_dK(fam, x[:h], x[h:N], x[:h], x[h:N], hyp[:-1])
+        Ky = K + np.abs(hyp[-1]) * np.diag(np.ones(N))
+        Kyinv = np.linalg.inv(Ky)
+        alpha = Kyinv.dot(y)
+        val = 0.5 * y.T.dot(alpha) + 0.5 * np.linalg.slogdet(Ky)[1]
+        grad = np.array([-0.5 * alpha.T.dot(dK[i].dot(alpha)) + 0.5 * np.trace(Kyinv.dot(dK[i])) for i in (0, 1)])
+        return val, grad
 
     def cholesky(self, Ky):
         A = np.array(Ky, dtype=np.float64, order="F")
@@ -133,6 +183,8 @@ class Oracle:
 
 
 _SCALARS = ("kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num")
+DL_NAMES = {4: "dkdlx_num", 5: "dkdly_num", 6: "d3kdxdx0dlx_num", 7: "d3kdydy0dlx_num", 8: "d3kdxdy0dlx_num",
+            9: "d3kdxdx0dly_num", 10: "d3kdydy0dly_num", 11: "d3kdxdy0dly_num"}
 
 
 class Ref:

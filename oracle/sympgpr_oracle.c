@@ -23,7 +23,10 @@
 
 enum { FAM_A = 0, FAM_B = 1, FAM_C = 2, FAM_D = 3 };
 /* which-codes of the scalar evaluator */
-enum { W_KERN = 0, W_DXDX0 = 1, W_DYDY0 = 2, W_DXDY0 = 3 };
+enum { W_KERN = 0, W_DXDX0 = 1, W_DYDY0 = 2, W_DXDY0 = 3,
+       /* length-scale derivatives (build_dK / build_dKreg, functions/func.py:52-129) */
+       W_DKDLX = 4, W_DKDLY = 5, W_DXDX0DLX = 6, W_DYDY0DLX = 7, W_DXDY0DLX = 8,
+       W_DXDX0DLY = 9, W_DYDY0DLY = 10, W_DXDY0DLY = 11 };
 
 /* ---- scalar kernels ------------------------------------------------------------------
  * Family A  periodic(q) x SE(P), product:
@@ -115,6 +118,86 @@ double orc_scalar(int fam, int which, double x_a, double y_a, double x_b, double
     }
     }
     return NAN;
+}
+
+/* Length-scale derivatives of the kernel and of its three Hessian entries, families A and C
+ * (the ones whose drivers call nll_grad: 02_pert_pendulum/main.py:55, 05_tokamak/SympGPR/main.py,
+ * 03_henon_heiles/main.py:155).  Expressions as generated:
+ *   A: python/05_tokamak/SympGPR/kernels.f90:135-231 (dkdlx, dkdly, d3kdxdx0dlx, d3kdydy0dlx,
+ *      d3kdxdy0dlx, d3kdxdx0dly, d3kdydy0dly, d3kdxdy0dly)
+ *   C: python/03_henon_heiles/kernels_sq.f90:124-217 */
+double orc_scalar_dl(int fam, int which, double x_a, double y_a, double x_b, double y_b,
+                     double lx, double ly)
+{
+    const double lx2 = lx * lx, ly2 = ly * ly;
+    const double dy = y_a - y_b;
+    if (fam == FAM_A) {
+        const double s = sin(0.5 * x_a - 0.5 * x_b), c = cos(0.5 * x_a - 0.5 * x_b);
+        const double cd = cos(1.0 * x_a - 1.0 * x_b);
+        const double Ek = exp(-0.5 * sq(dy) / ly2 - 0.5 * sq(s) / lx2);
+        const double E = exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(s)) / (lx2 * ly2));
+        switch (which) {
+        case W_DKDLX: return 1.0 * Ek * sq(s) / (lx2 * lx);
+        case W_DKDLY: return 1.0 * sq(dy) * Ek / (ly2 * ly);
+        case W_DXDX0DLX:
+            return (-0.5 * lx2 * lx2 * cd + lx2 * (0.75 * cd + 0.5) * sq(s) - 0.25 * sq(sq(s)) * sq(c)) * E /
+                   (lx2 * lx2 * lx2 * lx);
+        case W_DYDY0DLX: return 1.0 * (ly2 - sq(dy)) * E * sq(s) / (lx2 * lx * ly2 * ly2);
+        case W_DXDY0DLX: return (lx2 - 0.5 * sq(s)) * dy * E * s * c / (lx2 * lx2 * lx * ly2);
+        case W_DXDX0DLY: return 0.25 * sq(dy) * (lx2 * cd - sq(s) * sq(c)) * E / (lx2 * lx2 * ly2 * ly);
+        case W_DYDY0DLY:
+            return (-2.0 * ly2 * ly2 + 5.0 * ly2 * sq(dy) - 1.0 * sq(sq(dy))) * E / (ly2 * ly2 * ly2 * ly);
+        case W_DXDY0DLY: return (ly2 - 0.5 * sq(dy)) * dy * E * s * c / (lx2 * ly2 * ly2 * ly);
+        }
+    } else if (fam == FAM_C) {
+        const double dx = x_a - x_b;
+        const double Ek = exp(-0.5 * sq(dy) / ly2 - 0.5 * sq(dx) / lx2);
+        const double E = exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(dx)) / (lx2 * ly2));
+        switch (which) {
+        case W_DKDLX: return 1.0 * sq(dx) * Ek / (lx2 * lx);
+        case W_DKDLY: return 1.0 * sq(dy) * Ek / (ly2 * ly);
+        case W_DXDX0DLX:
+            return (-2.0 * lx2 * lx2 + 5.0 * lx2 * sq(dx) - 1.0 * sq(sq(dx))) * E / (lx2 * lx2 * lx2 * lx);
+        case W_DYDY0DLX: return 1.0 * (ly2 - sq(dy)) * sq(dx) * E / (lx2 * lx * ly2 * ly2);
+        case W_DXDY0DLX: return (2.0 * lx2 - 1.0 * sq(dx)) * dx * dy * E / (lx2 * lx2 * lx * ly2);
+        case W_DXDX0DLY: return 1.0 * (lx2 - sq(dx)) * sq(dy) * E / (lx2 * lx2 * ly2 * ly);
+        case W_DYDY0DLY:
+            return (-2.0 * ly2 * ly2 + 5.0 * ly2 * sq(dy) - 1.0 * sq(sq(dy))) * E / (ly2 * ly2 * ly2 * ly);
+        case W_DXDY0DLY: return (2.0 * ly2 - 1.0 * sq(dy)) * dx * dy * E / (lx2 * ly2 * ly2 * ly);
+        }
+    }
+    return NAN;
+}
+
+/* build_dK: python/functions/func.py:80-129.  which = 0 (d/dlx) or 1 (d/dly).  Output is
+ * (2 n0 x 2 n), column-major: rows index the "0" points, [[k11,k12],[k21,k22]], each
+ * sig * d3k(x0[k], y0[k], x[lk], y[lk]). */
+int orc_build_dk(int fam, int which, int n, int n0, const double *x, const double *y, const double *x0,
+                 const double *y0, const double *hyp, double *dK, size_t ld)
+{
+    const double lx = hyp[0], ly = hyp[1], sig = hyp[2];
+    const int wxx = which ? W_DXDX0DLY : W_DXDX0DLX, wyy = which ? W_DYDY0DLY : W_DYDY0DLX,
+              wxy = which ? W_DXDY0DLY : W_DXDY0DLX;
+    for (int lk = 0; lk < n; ++lk)
+        for (int k = 0; k < n0; ++k) {
+            dK[k + (size_t)lk * ld] = sig * orc_scalar_dl(fam, wxx, x0[k], y0[k], x[lk], y[lk], lx, ly);
+            dK[n0 + k + (size_t)lk * ld] = sig * orc_scalar_dl(fam, wxy, x0[k], y0[k], x[lk], y[lk], lx, ly);
+            dK[k + (size_t)(n + lk) * ld] = sig * orc_scalar_dl(fam, wxy, x0[k], y0[k], x[lk], y[lk], lx, ly);
+            dK[n0 + k + (size_t)(n + lk) * ld] = sig * orc_scalar_dl(fam, wyy, x0[k], y0[k], x[lk], y[lk], lx, ly);
+        }
+    return 0;
+}
+
+/* build_dKreg: python/functions/func.py:52-78.  Output (n x n0): Kp[k,lk] = sig dkdl(x0[lk],y0[lk],x[k],y[k]) */
+int orc_build_dkreg(int fam, int which, int n, int n0, const double *x, const double *y, const double *x0,
+                    const double *y0, const double *hyp, double *dK, size_t ld)
+{
+    const double lx = hyp[0], ly = hyp[1], sig = hyp[2];
+    for (int lk = 0; lk < n0; ++lk)
+        for (int k = 0; k < n; ++k)
+            dK[k + (size_t)lk * ld] =
+                sig * orc_scalar_dl(fam, which ? W_DKDLY : W_DKDLX, x0[lk], y0[lk], x[k], y[k], lx, ly);
+    return 0;
 }
 
 /* hyp layout of the reference: (lx, ly, sig) for A/B/C (sympgpr.f90:17, func.py:47-48

@@ -6,7 +6,7 @@ import numpy as np
 
 FAMILIES = {"A": 0, "B": 1, "C": 2, "D": 3}
 K_KERN, K_DXDX0, K_DYDY0, K_DXDY0 = 0, 1, 2, 3
-G_QQ, G_PQ, G_QP, G_PP, G_ALL, G_LOWER, G_OCML = 1, 2, 4, 8, 15, 16, 32
+G_QQ, G_PQ, G_QP, G_PP, G_ALL, G_LOWER, G_OCML, G_DLX, G_DLY = 1, 2, 4, 8, 15, 16, 32, 64, 128
 FIT_LOWER_ONLY, FIT_KEEP_K, FIT_REG = 1, 2, 4
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
@@ -34,6 +34,10 @@ SIGNATURES = {
     "sgpr_set_device": (C.c_int, [C.c_int]),
     "sgpr_build_k_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_size_t]),
     "sgpr_buildkreg_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_size_t]),
+    "sgpr_build_dk_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp,
+                                     C.c_size_t]),
+    "sgpr_build_dkreg_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp,
+                                        C.c_size_t]),
     "sgpr_kernel_eval_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "sgpr_potrf_host": (C.c_int, [C.c_int, _dp, C.c_size_t]),
     "sgpr_potrs_host": (C.c_int, [C.c_int, _dp, C.c_size_t, _dp, C.c_size_t, C.c_int]),
@@ -51,6 +55,7 @@ SIGNATURES = {
     "sgpr_fit_get_matrix": (C.c_int, [_vp, _dp, C.c_size_t]),
     "sgpr_fit_solve_rhs": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
     "sgpr_fit_predict_rows": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
+    "sgpr_fit_nll_grad": (C.c_int, [_vp, _dp]),
     "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
     "sgpr_fit_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
     "sgpr_fit_destroy": (C.c_int, [_vp]),

@@ -65,6 +65,17 @@ __global__ void copy_diag_kernel(int n, const double *A, size_t lda, double *d)
     if (i < n) d[i] = A[(size_t)i + (size_t)i * lda];
 }
 
+__global__ __launch_bounds__(256) void dot_kernel(int n, const double *a, size_t inca, const double *b, double *out)
+{
+    double q = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) q = __builtin_fma(a[(size_t)i * inca], b ? b[i] : 1.0, q);
+    __shared__ double sq[4];
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_down(q, o, 64);
+    if ((threadIdx.x & 63) == 0) sq[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sq[0] + sq[1] + sq[2] + sq[3];
+}
+
 __global__ void transpose_kernel(int m, int n, const double *A, size_t lda, double *B, size_t ldb)
 {
     __shared__ double tile[32][33];
@@ -171,6 +182,20 @@ int copy_diag(int n, const double *A, size_t lda, double *d, hipStream_t st)
 {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(copy_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, A, lda, d);
+    SGPR_CHECK_LAUNCH();
+    return 0;
+}
+
+int dot(int n, const double *a, const double *b, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, n, a, (size_t)1, b, out);
+    SGPR_CHECK_LAUNCH();
+    return 0;
+}
+
+int trace(int n, const double *A, size_t lda, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, n, A, lda + 1, (const double *)nullptr, out);
     SGPR_CHECK_LAUNCH();
     return 0;
 }

@@ -136,6 +136,60 @@ int sgpr_buildkreg_host(int family, int n, int n0, const double *x, const double
     return 0;
 }
 
+/* build_dK (functions/func.py:80-129), one length scale: dK is (2 n0 x 2 n), rows index the "0"
+ * points; entries sig * d3k..dl(x0[k], y0[k], x[lk], y[lk]).  Every entry is even under a <-> b,
+ * so the pair kernel is run with the "0" points as its row points. */
+int sgpr_build_dk_host(int family, int which, int n, int n0, const double *x, const double *y,
+                       const double *x0, const double *y0, const double *hyp, int nhyp, double *dK, size_t ld)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || n0 < 0 || ld < (size_t)(2 * n0) || (which != 0 && which != 1)) { set_error("build_dk: bad arguments"); return SGPR_E_ARG; }
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    if (n == 0 || n0 == 0) return 0;
+    DevBuf dx, dy, dx0, dy0, dD;
+    hipStream_t st = nullptr;
+    if ((rc = upload(dx, x, n, st)) || (rc = upload(dy, y, n, st)) || (rc = upload(dx0, x0, n0, st)) ||
+        (rc = upload(dy0, y0, n0, st)))
+        return rc;
+    const size_t l = 2 * (size_t)n0;
+    if ((rc = dD.alloc(l * 2 * n * sizeof(double)))) return rc;
+    double *d = dD.as<double>();
+    rc = gram_pairs(family, n0, n, dx0.as<double>(), dy0.as<double>(), dx.as<double>(), dy.as<double>(), kc, d,
+                    d + n0, d + l * n, d + n0 + l * n, l, 0, 0.0, SGPR_G_ALL | (which ? SGPR_G_DLY : SGPR_G_DLX), st);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dK, ld * sizeof(double), d, l * sizeof(double), l * sizeof(double), 2 * (size_t)n,
+                              hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+/* build_dKreg (functions/func.py:52-78): dK is (n x n0), Kp[k,lk] = sig dkdl(x0[lk], y0[lk], x[k], y[k]) */
+int sgpr_build_dkreg_host(int family, int which, int n, int n0, const double *x, const double *y,
+                          const double *x0, const double *y0, const double *hyp, int nhyp, double *dK, size_t ld)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || n0 < 0 || ld < (size_t)n || (which != 0 && which != 1)) { set_error("build_dkreg: bad arguments"); return SGPR_E_ARG; }
+    KConst kc;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    if (n == 0 || n0 == 0) return 0;
+    DevBuf dx, dy, dx0, dy0, dD;
+    hipStream_t st = nullptr;
+    if ((rc = upload(dx, x, n, st)) || (rc = upload(dy, y, n, st)) || (rc = upload(dx0, x0, n0, st)) ||
+        (rc = upload(dy0, y0, n0, st)))
+        return rc;
+    if ((rc = dD.alloc((size_t)n * n0 * sizeof(double)))) return rc;
+    rc = gram_reg(family, n, n0, dx.as<double>(), dy.as<double>(), dx0.as<double>(), dy0.as<double>(), kc,
+                  dD.as<double>(), (size_t)n, 0, 0.0, st, which ? DERIV_LY : DERIV_LX);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dK, ld * sizeof(double), dD.p, (size_t)n * sizeof(double), (size_t)n * sizeof(double),
+                              (size_t)n0, hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int sgpr_kernel_eval_host(int family, int which, int m, const double *xa, const double *ya,
                           const double *xb, const double *yb, const double *l, int nl, double *out)
 {
@@ -433,6 +487,48 @@ int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P,
     SGPR_HIP(hipMemcpyAsync(out_p, dop.p, m * sizeof(double), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipMemcpyAsync(out_q, doq.p, m * sizeof(double), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
+/* d nll / d(lx, ly) as nll_grad / nll_grad_reg compute it (functions/func.py:132-162):
+ *   grad_i = -1/2 alpha^T dK_i alpha + 1/2 tr(Ky^-1 dK_i).
+ * The reference forms Ky^-1 explicitly; here tr(Ky^-1 dK) = tr(L^-1 dK L^-T): W = dK, W := W L^-T
+ * (panel solve), W := W^T (= L^-1 dK by symmetry), W := W L^-T again, sum of the diagonal --
+ * 2 n^3 flop per length scale on the MFMA kernel, two n x n scratch matrices. */
+int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2)
+{
+    if (!f || !grad2) { set_error("null argument"); return SGPR_E_ARG; }
+    if (!f->solved) { set_error("fit_nll_grad: run the fit first"); return SGPR_E_STATE; }
+    const size_t n = (size_t)f->n;
+    const int N = f->npts;
+    DevBuf W, T, tmp, sc;
+    int rc;
+    if ((rc = W.alloc(n * n * sizeof(double))) || (rc = T.alloc(n * n * sizeof(double))) ||
+        (rc = tmp.alloc(n * sizeof(double))) || (rc = sc.alloc(4 * sizeof(double))))
+        return rc;
+    double *w = W.as<double>(), *t = T.as<double>(), *s = sc.as<double>();
+    for (int which = 0; which < 2; ++which) {
+        if (f->flags & SGPR_FIT_REG)
+            rc = gram_reg(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, w, n, 0, 0.0, f->st,
+                          which ? DERIV_LY : DERIV_LX);
+        else
+            rc = gram_pairs(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, w, w + N, w + n * N, w + N + n * N,
+                            n, 0, 0.0, SGPR_G_ALL | (which ? SGPR_G_DLY : SGPR_G_DLX), f->st);
+        if (rc) return rc;
+        // alpha^T dK alpha
+        SGPR_HIP(hipMemsetAsync(tmp.p, 0, n * sizeof(double), f->st));
+        if ((rc = gemv_n_sub(f->n, f->n, w, n, f->dalpha, tmp.as<double>(), f->st))) return rc;  // tmp = -dK alpha
+        if ((rc = dot(f->n, tmp.as<double>(), f->dalpha, s + 2 * which, f->st))) return rc;
+        // tr(L^-1 dK L^-T)
+        if ((rc = trsm_rlt(f->n, f->n, f->dA, n, w, n, f->work, f->st))) return rc;
+        if ((rc = transpose(f->n, f->n, w, n, t, n, f->st))) return rc;
+        if ((rc = trsm_rlt(f->n, f->n, f->dA, n, t, n, f->work, f->st))) return rc;
+        if ((rc = trace(f->n, t, n, s + 2 * which + 1, f->st))) return rc;
+    }
+    double h[4];
+    SGPR_HIP(hipMemcpyAsync(h, s, 4 * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    for (int which = 0; which < 2; ++which) grad2[which] = -0.5 * (-h[2 * which]) + 0.5 * h[2 * which + 1];
     return 0;
 }
 

@@ -28,7 +28,11 @@ struct KConst {
     double inv_lx2, inv_ly2;
     double cxx, cyy, cxy;   // sig*pp/lx^4, sig/ly^4, -sig*pm/(lx^2 ly^2)
     double hscale;          // 0.5 (family A/B) or p (family D); unused for C
+    // length-scale derivatives (build_dK / build_dKreg)
+    double inv_lx, inv_ly, inv_lx3, inv_ly3;
+    double gxx;             // sig*pp: kxx = gxx (cos2h/lx^2 - sc^2/lx^4) E  (A/D),  gxx (1/lx^2 - u/lx^4) E  (C)
 };
+enum { DERIV_NONE = 0, DERIV_LX = 1, DERIV_LY = 2 };
 int make_kconst(int family, const double *hyp, int nhyp, KConst *out);
 int make_kconst_l(int family, const double *l, int nl, KConst *out);  // sig = 1
 
@@ -38,7 +42,7 @@ int gram_pairs(int family, int mi, int mj, const double *xb, const double *yb, c
                size_t ld, long diag_off, double noise, unsigned flags, hipStream_t st);
 int gram_reg(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
              const double *ya, const KConst &kc, double *G, size_t ld, long diag_off, double noise,
-             hipStream_t st);
+             hipStream_t st, int deriv = DERIV_NONE);
 int kernel_eval(int family, int which, int m, const double *xa, const double *ya, const double *xb,
                 const double *yb, const KConst &kc, double *out, hipStream_t st);
 int predict_rows(int family, int m, const double *q, const double *P, int n0, const double *xtr,
@@ -76,6 +80,8 @@ int sym_fill_upper(int n, double *A, size_t lda, hipStream_t st);
 int nll_reduce(int n, const double *L, size_t ldl, const double *z, const double *alpha,
                double *dout /* [0]=0.5 z.alpha + sum log diag */, hipStream_t st);
 int copy_diag(int n, const double *A, size_t lda, double *d, hipStream_t st);
+int dot(int n, const double *a, const double *b, double *out, hipStream_t st);      // out[0] = a.b
+int trace(int n, const double *A, size_t lda, double *out, hipStream_t st);          // out[0] = sum A_ii
 int transpose(int m, int n, const double *A, size_t lda, double *B, size_t ldb, hipStream_t st);
 int gemv_n_sub(int m, int k, const double *A, size_t lda, const double *x, double *y,
                hipStream_t st);  // y(m) -= A(m x k) x(k)

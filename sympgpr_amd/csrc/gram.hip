@@ -84,6 +84,71 @@ __device__ __forceinline__ void pair_eval(double xa, double ya, double xb, doubl
     }
 }
 
+// d/dlx (DL = 1) or d/dly (DL = 2) of the three Hessian entries: the third-derivative kernels
+// d3kd..dl._num of kernels.f90:155-231 / kernels_sq.f90:146-217 in factored form.  With
+// E = exp(-u/2lx^2 - v/2ly^2), u = sin^2 h (A, D) or dx^2 (C), v = dy^2:
+//   d(g(l) E)/dlx = g'(lx) E + g E u/lx^3,   d(.)/dly = ... + g E v/ly^3.
+template <int FAM, int DL>
+__device__ __forceinline__ void pair_eval_d(double xa, double ya, double xb, double yb,
+                                            const KConst &kc, double &dxx, double &dxy, double &dyy)
+{
+    static_assert(FAM != SGPR_FAM_B, "length-scale derivatives are implemented for the product kernels");
+    const double dy = ya - yb;
+    const double v = dy * dy;
+    double u, E, kxx, kxy, kyy, gp;  // gp = g'(lx)/gxx for the xx entry
+    if constexpr (FAM == SGPR_FAM_C) {
+        const double dx = xa - xb;
+        u = dx * dx;
+        E = exp_fast(-0.5 * (v * kc.inv_ly2) - 0.5 * (u * kc.inv_lx2));
+        kxx = kc.cxx * (kc.lx2 - u) * E;
+        kxy = kc.cxy * (dx * dy) * E;
+        gp = (-2.0 + 4.0 * u * kc.inv_lx2) * kc.inv_lx3;           // d/dlx (1/lx^2 - u/lx^4)
+    } else {
+        const double h = kc.hscale * (xa - xb);
+        double s, c;
+        sincos_fast(h, s, c);
+        u = s * s;
+        const double sc = s * c;
+        const double cos2h = __builtin_fma(-2.0, u, 1.0);
+        E = exp_fast(-0.5 * (v * kc.inv_ly2) - 0.5 * (u * kc.inv_lx2));
+        kxx = kc.cxx * (kc.lx2 * cos2h - sc * sc) * E;
+        kxy = kc.cxy * (dy * sc) * E;
+        gp = (-2.0 * cos2h + 4.0 * (sc * sc) * kc.inv_lx2) * kc.inv_lx3;  // d/dlx (cos2h/lx^2 - sc^2/lx^4)
+    }
+    kyy = kc.cyy * (kc.ly2 - v) * E;
+    if constexpr (DL == DERIV_LX) {
+        const double w = u * kc.inv_lx3;
+        dxx = __builtin_fma(kxx, w, kc.gxx * gp * E);
+        dyy = kyy * w;
+        dxy = kxy * (w - 2.0 * kc.inv_lx);
+    } else {
+        const double w = v * kc.inv_ly3;
+        dxx = kxx * w;
+        dyy = __builtin_fma(kyy, w, kc.sig * ((-2.0 + 4.0 * v * kc.inv_ly2) * kc.inv_ly3) * E);
+        dxy = kxy * (w - 2.0 * kc.inv_ly);
+    }
+}
+
+// dk/dlx, dk/dly (dkdlx_num, dkdly_num: kernels.f90:135-154), without sig
+template <int FAM, int DL>
+__device__ __forceinline__ double kern_eval_d(double xa, double ya, double xb, double yb, const KConst &kc)
+{
+    static_assert(FAM != SGPR_FAM_B, "length-scale derivatives are implemented for the product kernels");
+    const double dy = ya - yb;
+    const double v = dy * dy;
+    double u;
+    if constexpr (FAM == SGPR_FAM_C) {
+        const double dx = xa - xb;
+        u = dx * dx;
+    } else {
+        double s, c;
+        sincos_fast(kc.hscale * (xa - xb), s, c);
+        u = s * s;
+    }
+    const double E = exp_fast(-0.5 * (v * kc.inv_ly2) - 0.5 * (u * kc.inv_lx2));
+    return DL == DERIV_LX ? E * u * kc.inv_lx3 : E * v * kc.inv_ly3;
+}
+
 // scalar kernel k(a, b) (kern_num): kernels.f90:1-11 and variants
 template <int FAM, bool OCML>
 __device__ __forceinline__ double kern_eval(double xa, double ya, double xb, double yb,
@@ -108,7 +173,23 @@ __device__ __forceinline__ double kern_eval(double xa, double ya, double xb, dou
     }
 }
 
-template <int FAM, bool OCML>
+template <int FAM, bool OCML, int DL>
+__device__ __forceinline__ void pair_any(double xa, double ya, double xb, double yb, const KConst &kc,
+                                         double &kxx, double &kxy, double &kyy)
+{
+    if constexpr (DL == DERIV_NONE) pair_eval<FAM, OCML>(xa, ya, xb, yb, kc, kxx, kxy, kyy);
+    else if constexpr (FAM == SGPR_FAM_B) { kxx = kxy = kyy = __builtin_nan(""); }
+    else pair_eval_d<FAM, DL>(xa, ya, xb, yb, kc, kxx, kxy, kyy);
+}
+template <int FAM, bool OCML, int DL>
+__device__ __forceinline__ double kern_any(double xa, double ya, double xb, double yb, const KConst &kc)
+{
+    if constexpr (DL == DERIV_NONE) return kern_eval<FAM, OCML>(xa, ya, xb, yb, kc);
+    else if constexpr (FAM == SGPR_FAM_B) return __builtin_nan("");
+    else return kern_eval_d<FAM, DL>(xa, ya, xb, yb, kc);
+}
+
+template <int FAM, bool OCML, int DL>
 __global__ __launch_bounds__(GT) void gram_pairs_kernel(const GramArgs a)
 {
     __shared__ double sxa[TJ], sya[TJ];
@@ -148,8 +229,8 @@ __global__ __launch_bounds__(GT) void gram_pairs_kernel(const GramArgs a)
         for (int jj = 0; jj < nj; ++jj) {
             const double xa = sxa[jj], ya = sya[jj];
             double kxx0, kxy0, kyy0, kxx1, kxy1, kyy1;
-            pair_eval<FAM, OCML>(xa, ya, xb0, yb0, a.kc, kxx0, kxy0, kyy0);
-            pair_eval<FAM, OCML>(xa, ya, xb1, yb1, a.kc, kxx1, kxy1, kyy1);
+            pair_any<FAM, OCML, DL>(xa, ya, xb0, yb0, a.kc, kxx0, kxy0, kyy0);
+            pair_any<FAM, OCML, DL>(xa, ya, xb1, yb1, a.kc, kxx1, kxy1, kyy1);
             const long j = j0 + jj;
             const double n0 = (d0 == j) ? noise : 0.0, n1 = (d0 + 1 == j) ? noise : 0.0;
             const size_t off = (size_t)i + (size_t)j * a.ld;
@@ -162,8 +243,8 @@ __global__ __launch_bounds__(GT) void gram_pairs_kernel(const GramArgs a)
         for (int jj = 0; jj < nj; ++jj) {
             const double xa = sxa[jj], ya = sya[jj];
             double kxx0, kxy0, kyy0, kxx1, kxy1, kyy1;
-            pair_eval<FAM, OCML>(xa, ya, xb0, yb0, a.kc, kxx0, kxy0, kyy0);
-            pair_eval<FAM, OCML>(xa, ya, xb1, yb1, a.kc, kxx1, kxy1, kyy1);
+            pair_any<FAM, OCML, DL>(xa, ya, xb0, yb0, a.kc, kxx0, kxy0, kyy0);
+            pair_any<FAM, OCML, DL>(xa, ya, xb1, yb1, a.kc, kxx1, kxy1, kyy1);
             const long j = j0 + jj;
             const double n0 = (d0 == j) ? noise : 0.0, n1 = (d0 + 1 == j) ? noise : 0.0;
             const size_t off = (size_t)i + (size_t)j * a.ld;
@@ -193,7 +274,7 @@ struct RegArgs {
     KConst kc;
 };
 
-template <int FAM, bool OCML>
+template <int FAM, bool OCML, int DL>
 __global__ __launch_bounds__(GT) void gram_reg_kernel(const RegArgs a)
 {
     __shared__ double sxa[TJ], sya[TJ];
@@ -215,9 +296,9 @@ __global__ __launch_bounds__(GT) void gram_reg_kernel(const RegArgs a)
     for (int jj = 0; jj < nj; ++jj) {
         const double xa = sxa[jj], ya = sya[jj];
         const long j = j0 + jj;
-        const double k0 = a.kc.sig * kern_eval<FAM, OCML>(xa, ya, xb0, yb0, a.kc) +
+        const double k0 = a.kc.sig * kern_any<FAM, OCML, DL>(xa, ya, xb0, yb0, a.kc) +
                           ((d0 == j) ? a.noise : 0.0);
-        const double k1 = a.kc.sig * kern_eval<FAM, OCML>(xa, ya, xb1, yb1, a.kc) +
+        const double k1 = a.kc.sig * kern_any<FAM, OCML, DL>(xa, ya, xb1, yb1, a.kc) +
                           ((d0 + 1 == j) ? a.noise : 0.0);
         const size_t off = (size_t)i + (size_t)j * a.ld;
         if (vec) {
@@ -346,6 +427,11 @@ int make_kconst(int family, const double *hyp, int nhyp, KConst *out)
     k.cyy = k.sig / (k.ly2 * k.ly2);
     k.cxy = -k.sig * pm / (k.lx2 * k.ly2);
     k.hscale = family == SGPR_FAM_D ? k.p : 0.5;
+    k.inv_lx = 1.0 / k.lx;
+    k.inv_ly = 1.0 / k.ly;
+    k.inv_lx3 = 1.0 / (k.lx2 * k.lx);
+    k.inv_ly3 = 1.0 / (k.ly2 * k.ly);
+    k.gxx = k.sig * pp;
     *out = k;
     return 0;
 }
@@ -385,10 +471,17 @@ int gram_pairs(int family, int mi, int mj, const double *xb, const double *yb, c
     const dim3 grid((mi + TI - 1) / TI, (mj + TJ - 1) / TJ);
     if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
     const bool ocml = flags & SGPR_G_OCML;
+    const int deriv = (flags & SGPR_G_DLX) ? DERIV_LX : ((flags & SGPR_G_DLY) ? DERIV_LY : DERIV_NONE);
+    if (deriv != DERIV_NONE && family == SGPR_FAM_B) {
+        set_error("length-scale derivatives are not available for the sum kernel (family B)");
+        return SGPR_E_ARG;
+    }
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
-        if (ocml) hipLaunchKernelGGL((gram_pairs_kernel<F, true>), grid, dim3(GT), 0, st, a);
-        else      hipLaunchKernelGGL((gram_pairs_kernel<F, false>), grid, dim3(GT), 0, st, a);
+        if (deriv == DERIV_LX)      hipLaunchKernelGGL((gram_pairs_kernel<F, false, DERIV_LX>), grid, dim3(GT), 0, st, a);
+        else if (deriv == DERIV_LY) hipLaunchKernelGGL((gram_pairs_kernel<F, false, DERIV_LY>), grid, dim3(GT), 0, st, a);
+        else if (ocml) hipLaunchKernelGGL((gram_pairs_kernel<F, true, DERIV_NONE>), grid, dim3(GT), 0, st, a);
+        else           hipLaunchKernelGGL((gram_pairs_kernel<F, false, DERIV_NONE>), grid, dim3(GT), 0, st, a);
         SGPR_CHECK_LAUNCH();
         return 0;
     });
@@ -396,8 +489,12 @@ int gram_pairs(int family, int mi, int mj, const double *xb, const double *yb, c
 
 int gram_reg(int family, int mi, int mj, const double *xb, const double *yb, const double *xa,
              const double *ya, const KConst &kc, double *G, size_t ld, long diag_off, double noise,
-             hipStream_t st)
+             hipStream_t st, int deriv)
 {
+    if (deriv != DERIV_NONE && family == SGPR_FAM_B) {
+        set_error("length-scale derivatives are not available for the sum kernel (family B)");
+        return SGPR_E_ARG;
+    }
     if (mi < 0 || mj < 0) { set_error("negative extent"); return SGPR_E_ARG; }
     if (mi == 0 || mj == 0) return 0;
     if (ld < (size_t)mi) { set_error("ld smaller than the tile's row count"); return SGPR_E_ARG; }
@@ -406,7 +503,9 @@ int gram_reg(int family, int mi, int mj, const double *xb, const double *yb, con
     if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
-        hipLaunchKernelGGL((gram_reg_kernel<F, false>), grid, dim3(GT), 0, st, a);
+        if (deriv == DERIV_LX)      hipLaunchKernelGGL((gram_reg_kernel<F, false, DERIV_LX>), grid, dim3(GT), 0, st, a);
+        else if (deriv == DERIV_LY) hipLaunchKernelGGL((gram_reg_kernel<F, false, DERIV_LY>), grid, dim3(GT), 0, st, a);
+        else                        hipLaunchKernelGGL((gram_reg_kernel<F, false, DERIV_NONE>), grid, dim3(GT), 0, st, a);
         SGPR_CHECK_LAUNCH();
         return 0;
     });

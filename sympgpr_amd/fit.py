@@ -74,6 +74,12 @@ class SympFit:
         L.check(self._lib.sgpr_fit_nll(self._h, C.cast(C.byref(v), L._dp)), "sgpr_fit_nll")
         return v.value
 
+    def nll_grad(self):
+        """d nll / d(lx, ly) (functions/func.py:132-162: nlp_grad) on a solved fit."""
+        g = np.empty(2)
+        L.check(self._lib.sgpr_fit_nll_grad(self._h, L.dptr(g)), "sgpr_fit_nll_grad")
+        return g
+
     def ldiag(self):
         out = np.empty(self.n)
         L.check(self._lib.sgpr_fit_ldiag(self._h, L.dptr(out)), "sgpr_fit_ldiag")

@@ -11,7 +11,7 @@ order, in-place semantics and error behaviour -- with the hot path on the MI355X
 
 Select the kernel family (which kernels*.f90 the reference would have compiled) with
 `set_family("A"|"B"|"C"|"D")`; default "A" (python/05_tokamak/SympGPR/kernels.f90).
-Not mirrored yet: build_dK, build_dKreg, nll_grad, nll_grad_reg.
+build_dK / build_dKreg / nll_grad / nll_grad_reg are available for the product kernels (A, C, D).
 """
 import numpy as np
 
@@ -19,6 +19,7 @@ from . import kernels as _kernels
 from .fit import SympFit
 from .fortran.sympgpr import sympgpr
 from .kernels import *  # noqa: F401,F403  (kern_num, d2kdxdx0_num, ... like `from kernels import *`, func.py:15)
+from . import ops as _ops
 from .ops import cholesky as _cholesky
 from .ops import get_family, set_family, solve_cholesky as _solve_cholesky  # noqa: F401
 from .predict import Predictor, solve_implicit_P
@@ -177,15 +178,37 @@ def quality(qmap, pmap, H, ysint, Ntest, Nm):
     return Eosc, gd, stdgd
 
 
-def _not_yet(name):
-    def f(*a, **k):
-        raise NotImplementedError(name + " is not part of the accelerated path yet (SURVEY.md 8(f) rank 2: "
-                                  "hyper-parameter gradients need the third-derivative kernels on the device)")
-    f.__name__ = name
-    return f
+def build_dKreg(xin, x0in, hyp):
+    """functions/func.py:52-78 -> [dK/dlx, dK/dly], each (N x N0)."""
+    N = len(xin) // 2
+    N0 = len(x0in) // 2
+    return _ops.build_dkreg(xin[0:N], xin[N:2 * N], x0in[0:N0], x0in[N0:2 * N0], hyp)
 
 
-build_dKreg = _not_yet("build_dKreg")
-build_dK = _not_yet("build_dK")
-nll_grad_reg = _not_yet("nll_grad_reg")
-nll_grad = _not_yet("nll_grad")
+def build_dK(xin, x0in, hyp):
+    """functions/func.py:80-129 -> [dK/dlx, dK/dly], each (2 N0 x 2 N), rows over the "0" points."""
+    N = len(xin) // 2
+    N0 = len(x0in) // 2
+    return _ops.build_dk(xin[0:N], xin[N:2 * N], x0in[0:N0], x0in[N0:2 * N0], hyp)
+
+
+def nll_grad_reg(hyp, x, y, N):
+    """functions/func.py:132-146 -> (nlp_val, nlp_grad[2]).  The reference inverts Ky and takes
+    slogdet; 0.5 slogdet(Ky) = sum log diag L, so the value is the one nll_chol_reg returns."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    with SympFit(get_family(), x[0:N], x[N:2 * N], np.asarray(y, dtype=np.float64)[:N], hyp[:-1],
+                 np.abs(hyp[-1]), reg=True, lower_only=False) as f:
+        f.run()
+        return f.nll(), f.nll_grad()
+
+
+def nll_grad(hyp, x, y, N):
+    """functions/func.py:148-162 -> (nlp_val, nlp_grad[2])."""
+    hyp = np.asarray(hyp, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    npts = N // 2
+    with SympFit(get_family(), x[0:npts], x[npts:2 * npts], np.asarray(y, dtype=np.float64)[:2 * npts],
+                 hyp[:-1], np.abs(hyp[-1]), lower_only=False) as f:
+        f.run()
+        return f.nll(), f.nll_grad()

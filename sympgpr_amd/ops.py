@@ -98,3 +98,33 @@ def solve_cholesky(Lfac, b):
     nrhs = 1 if B.ndim == 1 else B.shape[1]
     L.check(lib.sgpr_potrs_host(n, L.dptr(Lf), max(n, 1), L.dptr(B), max(n, 1), nrhs), "sgpr_potrs_host")
     return B
+
+
+def build_dk(x, y, x0, y0, hyp, family=None):
+    """[dK/dlx, dK/dly], each (2 N0 x 2 N): build_dK of functions/func.py:80-129."""
+    lib = L.load_library()
+    x, y, x0, y0, hyp = map(L.f64, (np.atleast_1d(x), np.atleast_1d(y), np.atleast_1d(x0), np.atleast_1d(y0), hyp))
+    n, n0 = len(x), len(x0)
+    out = []
+    for which in (0, 1):
+        D = np.empty((2 * n0, 2 * n), order="F")
+        L.check(lib.sgpr_build_dk_host(L.family_id(family or _FAMILY), which, n, n0, L.dptr(x), L.dptr(y),
+                                       L.dptr(x0), L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(D), max(2 * n0, 1)),
+                "sgpr_build_dk_host")
+        out.append(D)
+    return out
+
+
+def build_dkreg(x, y, x0, y0, hyp, family=None):
+    """[dK/dlx, dK/dly], each (N x N0): build_dKreg of functions/func.py:52-78."""
+    lib = L.load_library()
+    x, y, x0, y0, hyp = map(L.f64, (np.atleast_1d(x), np.atleast_1d(y), np.atleast_1d(x0), np.atleast_1d(y0), hyp))
+    n, n0 = len(x), len(x0)
+    out = []
+    for which in (0, 1):
+        D = np.empty((n, n0), order="F")
+        L.check(lib.sgpr_build_dkreg_host(L.family_id(family or _FAMILY), which, n, n0, L.dptr(x), L.dptr(y),
+                                          L.dptr(x0), L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(D), max(n, 1)),
+                "sgpr_build_dkreg_host")
+        out.append(D)
+    return out

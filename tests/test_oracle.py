@@ -119,3 +119,40 @@ def test_multi_rhs_solve(oracle, fits):
     B = np.random.default_rng(0).standard_normal((64, 5))
     X = oracle.solve_cholesky(L, B)
     assert np.abs(Ky @ X - B).max() < 1e-10
+
+
+def test_length_scale_derivative_kernels_vs_reference_fortran(oracle):
+    """the eight d../dl functions build_dK / build_dKreg use (kernels.f90:135-231,
+    kernels_sq.f90:124-217), restated in the oracle, against the reference's compiled Fortran."""
+    from oracle.oracle import Ref, DL_NAMES
+    if not Ref.available():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    ref = Ref()
+    rng = np.random.default_rng(3)
+    for fam in "AC":
+        for _ in range(100):
+            a = rng.uniform(-3, 3, 4)
+            lx, ly = rng.uniform(0.3, 2, 2)
+            for w, name in DL_NAMES.items():
+                v, r = oracle.scalar_dl(fam, w, *a, lx, ly), ref.scalar(fam, name, *a, lx, ly)
+                assert abs(v - r) <= 1e-12 * max(abs(r), 1e-3)
+
+
+def test_nll_grad_is_the_gradient(oracle):
+    """functions/func.py:148-162 restated in the oracle: nlp_grad against central differences
+    of nlp_val in (lx, ly)."""
+    rng = np.random.default_rng(5)
+    Np = 12
+    x = np.hstack((rng.uniform(0, 2 * np.pi, Np), rng.uniform(-2, 2, Np)))
+    y = rng.standard_normal(2 * Np)
+    hyp = np.array([0.9, 1.1, 0.7, 1e-2])
+    for fam in "AC":
+        val, g = oracle.nll_grad(fam, hyp, x, y, 2 * Np)
+        for i in (0, 1):
+            h = 1e-6
+            hp, hm = hyp.copy(), hyp.copy()
+            hp[i] += h; hm[i] -= h
+            fd = (oracle.nll_grad(fam, hp, x, y, 2 * Np)[0] - oracle.nll_grad(fam, hm, x, y, 2 * Np)[0]) / (2 * h)
+            assert g[i] == pytest.approx(fd, rel=1e-6, abs=1e-7)
+        alpha, nll, _ = oracle.fit(fam, x[:Np], x[Np:], y, hyp[:3], hyp[3])
+        assert val == pytest.approx(nll, rel=1e-12)
