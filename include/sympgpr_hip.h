@@ -188,6 +188,16 @@ int sgpr_predict_rows_dev(int family, int m, const double *q, const double *P, i
 int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, int n0,
                          const double *xtrain, const double *ytrain, const double *hyp, int nhyp,
                          const double *alpha, double *out, void *stream);
+/* applymap / applymap_henon (functions/func.py:216-260; calcP / calcQ / guessP of sympgpr.f90:62-125
+ * inlined) for all Ntest orbits with every time step on the device: one workgroup per orbit, the
+ * implicit equation for P solved by a secant iteration from the regular-GP guess (tol 1e-13 like
+ * hybrd1), q optionally wrapped mod 2 pi.  alpha = Kyinv ztrain, alphap = Kyinvp ztrainp.
+ * qmap, pmap: [nm][ntest] C-ordered; a NaN marks a lost orbit from that step on. */
+int sgpr_applymap_host(int family, int wrap, int nm, int ntest, const double *hyp, int nhyp, int n0,
+                       const double *xtrain, const double *ytrain, const double *alpha,
+                       const double *hypp, int nhypp, int n0p, const double *xtrainp,
+                       const double *ytrainp, const double *alphap, const double *Q0,
+                       const double *P0, double *qmap, double *pmap);
 /* alpha-solve on device with the factor and its leaf inverses: b (n) := L^-T L^-1 b */
 int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b,
                        void *stream);

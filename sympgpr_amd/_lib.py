@@ -82,6 +82,8 @@ SIGNATURES = {
     "sgpr_predict_rows_dev": (C.c_int, [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp,
                                         _vp]),
     "sgpr_predict_reg_dev": (C.c_int, [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp]),
+    "sgpr_applymap_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
+                                     C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
 }
 

@@ -659,6 +659,37 @@ int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, in
     return predict_reg(family, m, q, P, n0, xtrain, ytrain, kc, alpha, out, static_cast<hipStream_t>(stream));
 }
 
+/* applymap / applymap_henon (functions/func.py:216-260) for all Ntest orbits, every time step on
+ * the device.  alpha = Kyinv ztrain (2 n0), alphap = Kyinvp ztrainp (n0p); qmap, pmap: [nm][ntest]
+ * C-ordered host arrays (row 0 = initial conditions).  wrap != 0: q mod 2 pi. */
+int sgpr_applymap_host(int family, int wrap, int nm, int ntest, const double *hyp, int nhyp, int n0,
+                       const double *xtrain, const double *ytrain, const double *alpha, const double *hypp,
+                       int nhypp, int n0p, const double *xtrainp, const double *ytrainp, const double *alphap,
+                       const double *Q0, const double *P0, double *qmap, double *pmap)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (nm < 1 || ntest < 0 || n0 < 0 || n0p < 0) { set_error("applymap: bad arguments"); return SGPR_E_ARG; }
+    KConst kc, kcp;
+    if ((rc = make_kconst(family, hyp, nhyp, &kc)) || (rc = make_kconst(family, hypp, nhypp, &kcp))) return rc;
+    if (ntest == 0) return 0;
+    DevBuf x, y, al, xp, yp, alp, q0, p0, qm, pm;
+    hipStream_t st = nullptr;
+    if ((rc = upload(x, xtrain, n0, st)) || (rc = upload(y, ytrain, n0, st)) || (rc = upload(al, alpha, 2 * (size_t)n0, st)) ||
+        (rc = upload(xp, xtrainp, n0p, st)) || (rc = upload(yp, ytrainp, n0p, st)) || (rc = upload(alp, alphap, n0p, st)) ||
+        (rc = upload(q0, Q0, ntest, st)) || (rc = upload(p0, P0, ntest, st)) ||
+        (rc = qm.alloc((size_t)nm * ntest * sizeof(double))) || (rc = pm.alloc((size_t)nm * ntest * sizeof(double))))
+        return rc;
+    rc = applymap(family, wrap, nm, ntest, n0, x.as<double>(), y.as<double>(), kc, al.as<double>(), n0p,
+                  xp.as<double>(), yp.as<double>(), kcp, alp.as<double>(), q0.as<double>(), p0.as<double>(),
+                  qm.as<double>(), pm.as<double>(), st);
+    if (rc) return rc;
+    SGPR_HIP(hipMemcpyAsync(qmap, qm.p, (size_t)nm * ntest * sizeof(double), hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipMemcpyAsync(pmap, pm.p, (size_t)nm * ntest * sizeof(double), hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int sgpr_profile_begin(void) { gemm_profile_begin(); return 0; }
 int sgpr_profile_end(double *out8)
 {

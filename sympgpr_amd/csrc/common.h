@@ -52,6 +52,11 @@ int predict_reg(int family, int m, const double *q, const double *P, int n0, con
                 const double *ytr, const KConst &kc, const double *alpha, double *out,
                 hipStream_t st);
 
+int applymap(int family, int wrap, int nm, int ntest, int n0, const double *xtr, const double *ytr,
+             const KConst &kc, const double *alpha, int n0p, const double *xtrp, const double *ytrp,
+             const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
+             double *pmap, hipStream_t st);
+
 // ---- gemm_f64.hip : C = beta C + alpha A B^T on fp64 MFMA tiles
 int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
             size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,

@@ -390,6 +390,96 @@ __global__ __launch_bounds__(GT) void predict_reg_kernel(int n0, const double *q
     }
 }
 
+// ---- applymap: the whole symplectic-map iteration of one orbit inside one workgroup ------------
+// functions/func.py:216-260 (applymap / applymap_henon) with calcP / calcQ / guessP of
+// sympgpr.f90:62-125 inlined: per time step, P_new is the root of f(P) = pGP(q, P) - p + P started
+// from the regular-GP guess (the reference runs MINPACK hybrd1, tol 1e-13, per point and step, each
+// residual an O(n^2) matmul with Kyinv); here alpha = Kyinv ztrain is cached, a residual is one
+// block-wide reduction over the training points, and all nm steps run without leaving the GPU.
+struct MapArgs {
+    int nm, ntest, n0, n0p, wrap, maxiter;
+    double tol;
+    const double *xtr, *ytr, *alpha;      // symplectic GP: n0 points, alpha 2 n0
+    const double *xtrp, *ytrp, *alphap;   // regular GP (guess): n0p points
+    const double *Q0, *P0;
+    double *qmap, *pmap;                  // [nm][ntest], C order (numpy zeros([nm, Ntest]))
+    KConst kc, kcp;
+};
+
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_down(a, o, 64);
+        b += __shfl_down(b, o, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sh[2 * (threadIdx.x >> 6)] = a;
+        sh[2 * (threadIdx.x >> 6) + 1] = b;
+    }
+    __syncthreads();
+    a = sh[0] + sh[2] + sh[4] + sh[6];
+    b = sh[1] + sh[3] + sh[5] + sh[7];
+}
+
+template <int FAM>
+__global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
+{
+    __shared__ double sh[8];
+    const int k = blockIdx.x;
+    auto rows = [&](double q, double P, double &r1, double &r2) {   // Kstar(1,:).alpha, Kstar(2,:).alpha
+        r1 = 0.0; r2 = 0.0;
+        for (int j = threadIdx.x; j < a.n0; j += GT) {
+            double kxx, kxy, kyy;
+            pair_eval<FAM, false>(a.xtr[j], a.ytr[j], q, P, a.kc, kxx, kxy, kyy);
+            const double a1 = a.alpha[j], a2 = a.alpha[a.n0 + j];
+            r1 += kxx * a1 + kxy * a2;
+            r2 += kxy * a1 + kyy * a2;
+        }
+        block_sum2(r1, r2, sh);
+    };
+    auto guess = [&](double q, double p) {
+        double r = 0.0, z = 0.0;
+        for (int j = threadIdx.x; j < a.n0p; j += GT)
+            r += a.kcp.sig * kern_eval<FAM, false>(a.xtrp[j], a.ytrp[j], q, p, a.kcp) * a.alphap[j];
+        block_sum2(r, z, sh);
+        return r;
+    };
+    double q = a.Q0[k], p = a.P0[k];
+    if (threadIdx.x == 0) { a.qmap[k] = q; a.pmap[k] = p; }
+    const double nan = __builtin_nan("");
+    for (int i = 0; i + 1 < a.nm; ++i) {
+        double qn = nan, pn = nan;
+        if (!(q != q) && !(p != p)) {                      // NaN = lost orbit stays lost (func.py:231-232)
+            double P0 = guess(q, p), r1, r2;
+            rows(q, P0, r1, r2);
+            double f0 = r1 - p + P0;
+            double P1 = P0 - f0;                            // f'(P) ~ 1 near the identity map
+            rows(q, P1, r1, r2);
+            double f1 = r1 - p + P1;
+            for (int it = 0; it < a.maxiter; ++it) {        // secant; every quantity is block-uniform
+                if (!(fabs(P1 - P0) > a.tol * fmax(1.0, fabs(P1))) || !(f1 == f1)) break;
+                const double d = f1 - f0;
+                if (d == 0.0) break;
+                const double Pn = P1 - f1 * (P1 - P0) / d;
+                P0 = P1; f0 = f1; P1 = Pn;
+                rows(q, P1, r1, r2);
+                f1 = r1 - p + P1;
+            }
+            if ((f1 == f1) && fabs(f1) <= 1e-8 * fmax(1.0, fabs(p))) {
+                pn = P1;
+                qn = r2 + q;                                 // Eq. (43): Delta q from the same evaluation
+                if (a.wrap) qn -= 6.283185307179586477 * floor(qn / 6.283185307179586477);
+            }
+        }
+        q = qn; p = pn;
+        if (threadIdx.x == 0) {
+            a.qmap[(size_t)(i + 1) * a.ntest + k] = q;
+            a.pmap[(size_t)(i + 1) * a.ntest + k] = p;
+        }
+    }
+}
+
 template <typename F>
 int dispatch_family(int family, F &&f)
 {
@@ -534,6 +624,21 @@ int predict_rows(int family, int m, const double *q, const double *P, int n0, co
         constexpr int F = decltype(fam)::value;
         hipLaunchKernelGGL((predict_rows_kernel<F>), dim3(m), dim3(GT), 0, st, n0, q, P, xtr, ytr,
                            kc, alpha, out_p, out_q);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+int applymap(int family, int wrap, int nm, int ntest, int n0, const double *xtr, const double *ytr,
+             const KConst &kc, const double *alpha, int n0p, const double *xtrp, const double *ytrp,
+             const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
+             double *pmap, hipStream_t st)
+{
+    if (nm <= 0 || ntest <= 0) return 0;
+    MapArgs a{nm, ntest, n0, n0p, wrap, 60, 1e-13, xtr, ytr, alpha, xtrp, ytrp, alphap, Q0, P0, qmap, pmap, kc, kcp};
+    return dispatch_family(family, [&](auto fam) {
+        constexpr int F = decltype(fam)::value;
+        hipLaunchKernelGGL((applymap_kernel<F>), dim3(ntest), dim3(GT), 0, st, a);
         SGPR_CHECK_LAUNCH();
         return 0;
     });

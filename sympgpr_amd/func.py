@@ -124,33 +124,25 @@ def calcP(x, y, l, hypp, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv):
 
 
 def _applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv, wrap):
-    """Same recurrences as the reference's double loop (functions/func.py:216-237), with the
-    Ntest orbits of a time step evaluated as one device batch and alpha = Kyinv ztrain formed
-    once instead of inside every calcP / calcQ call."""
+    """The recurrences of the reference's double loop (functions/func.py:216-237) with all nm steps
+    of all Ntest orbits inside one device launch (sgpr_applymap_host): alpha = Kyinv ztrain is
+    formed once instead of inside every calcP / calcQ call."""
+    from . import _lib as L
+    lib = L.load_library()
     Ntrain, Ntrainp = len(xtrain) // 2, len(xtrainp) // 2
-    fam = get_family()
-    pred = Predictor(fam, xtrain[:Ntrain], xtrain[Ntrain:], l, np.asarray(Kyinv) @ np.asarray(ztrain))
-    predp = Predictor(fam, xtrainp[:Ntrainp], xtrainp[Ntrainp:], hypp, np.asarray(Kyinvp) @ np.asarray(ztrainp),
-                      reg=True)
+    f = L.f64
+    xt, yt = f(xtrain[:Ntrain]), f(xtrain[Ntrain:2 * Ntrain])
+    xp, yp = f(xtrainp[:Ntrainp]), f(xtrainp[Ntrainp:2 * Ntrainp])
+    alpha = f(np.asarray(Kyinv, dtype=np.float64) @ np.asarray(ztrain, dtype=np.float64))
+    alphap = f(np.asarray(Kyinvp, dtype=np.float64) @ np.asarray(ztrainp, dtype=np.float64))
+    hyp, hypp = f(l), f(hypp)
+    Q0, P0 = f(np.broadcast_to(Q0map, (Ntest,))), f(np.broadcast_to(P0map, (Ntest,)))
     pmap = np.zeros([nm, Ntest])
     qmap = np.zeros([nm, Ntest])
-    pmap[0, :] = P0map
-    qmap[0, :] = Q0map
-    for i in range(0, nm - 1):
-        ok = ~np.isnan(pmap[i, :]) & ~np.isnan(qmap[i, :])
-        pmap[i + 1, :] = np.nan
-        qmap[i + 1, :] = np.nan
-        if not ok.any():
-            continue
-        # new P including Newton for the implicit Eq. (42), then Q from Eq. (43)
-        Pn = solve_implicit_P(pred, predp, qmap[i, ok], pmap[i, ok])
-        pmap[i + 1, ok] = Pn
-        good = ok.copy()
-        good[ok] = ~np.isnan(Pn)
-        if good.any():
-            dq = pred(qmap[i, good], pmap[i + 1, good])[1]
-            qn = dq + qmap[i, good]
-            qmap[i + 1, good] = np.mod(qn, 2.0 * np.pi) if wrap else qn
+    L.check(lib.sgpr_applymap_host(L.family_id(get_family()), int(bool(wrap)), nm, Ntest, L.dptr(hyp), len(hyp),
+                                   Ntrain, L.dptr(xt), L.dptr(yt), L.dptr(alpha), L.dptr(hypp), len(hypp), Ntrainp,
+                                   L.dptr(xp), L.dptr(yp), L.dptr(alphap), L.dptr(Q0), L.dptr(P0), L.dptr(qmap),
+                                   L.dptr(pmap)), "sgpr_applymap_host")
     return qmap, pmap
 
 
