@@ -10,9 +10,10 @@ on grid position (I mod pr, J mod pc).  Per panel step K of the right-looking fa
     everyone:            pr broadcasts deliver the panel pieces of the pr process rows (RCCL
                          broadcast over xGMI); the pieces needed as the column operand are
                          regrouped by block
-    everyone:            local trailing update A(I,J) -= L(I,K) L(J,K)^T on the blocks it owns,
-                         one sgpr_gemm_nt_bc_dev call (fp64 MFMA), tiles above the global
-                         diagonal skipped
+    everyone:            local trailing update A(I,J) -= L(I,K) L(J,K)^T on the blocks it owns
+                         (sgpr_gemm_nt_bc_dev, fp64 MFMA, tiles above the global diagonal
+                         skipped) -- block column K+1 first, so that panel K+1 can be factored
+                         and broadcast (asynchronously) underneath the bulk of update K
 
 The Gram build needs no communication: every rank evaluates exactly the pairs of the blocks it
 owns (inputs are replicated, 16 N bytes).  The triangular solves keep b replicated and exchange
@@ -176,71 +177,109 @@ class DistFit:
                 blk.diagonal().add_(self.sig2n)
 
     # ------------------------------------------------------------------ factorisation
-    def factor(self):
+    def _panel_start(self, K):
+        """Factor the diagonal block K, solve its panel, START the broadcasts of the panel pieces
+        (one per process row, asynchronous).  Returns (pieces, handles)."""
         ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
+        kI, kJ = K % pr, K % pc
+        lj_K = K // pc
+        if (pi, pj) == (kI, kJ):
+            li_K = K // pr
+            blk = self.A2[lj_K * nb:(lj_K + 1) * nb, li_K * nb:(li_K + 1) * nb]
+            self.Lkk.view(nb, nb).copy_(blk)
+            ops.potrf(nb, self.Lkk, self.wbuf, self.info_t)
+            # LAPACK-style global index of the first failing minor, tracked on the device
+            cand = torch.where(self.info_t[:1] != 0, self.info_t[:1].to(torch.int64) + K * nb,
+                               torch.full_like(self.fail_t, self._BIG))
+            self.fail_t = torch.minimum(self.fail_t, cand)
+            blk.copy_(self.Lkk.view(nb, nb))
+            self.work[K] = self.wbuf.clone()
+        li0 = _count_le(K, pi, pr)            # first local block row with I > K
+        m_p = self.mloc - li0 * nb
+        if pj == kJ:
+            src = self.grank(kI, kJ)
+            dist.broadcast(self.Lkk, src=src, group=self.col_groups[kJ])
+            dist.broadcast(self.wbuf, src=src, group=self.col_groups[kJ])
+            if m_p > 0:
+                ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, li0 * nb + lj_K * nb * self.mloc, self.mloc)
+        pieces, handles = [], []
+        for q in range(pr):
+            lq0 = _count_le(K, q, pr)
+            nblk_q = len(range(q, self.nbk, pr)) - lq0
+            P = ops.empty(nblk_q * nb * nb)
+            if nblk_q > 0:
+                if (pi, pj) == (q, kJ):
+                    P.view(nb, nblk_q * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, lq0 * nb:])
+                handles.append(dist.broadcast(P, src=self.grank(q, kJ), group=self.group, async_op=True))
+            pieces.append((P, nblk_q, lq0))
+        return pieces, handles
+
+    def _operands(self, K, pieces):
+        """Row / column operands of this rank's trailing update for panel K."""
+        ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
+        Lrow, nrow_blk, _ = pieces[pi]
+        lj0 = _count_le(K, pj, pc)            # first local block column with J > K
+        ncol_blk = len(self.cols) - lj0
+        if nrow_blk == 0 or ncol_blk == 0:
+            return None
+        Lcol = ops.empty(ncol_blk * nb * nb)
+        Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
+        for q in range(pr):
+            P, nblk_q, lq0 = pieces[q]
+            if nblk_q == 0:
+                continue
+            t_idx, p_idx = [], []
+            for t in range(ncol_blk):
+                J = self.cols[lj0 + t]
+                if J % pr == q:
+                    t_idx.append(t)
+                    p_idx.append(J // pr - lq0)
+            if t_idx:
+                ti = torch.as_tensor(t_idx, device=Lcol.device)
+                pidx = torch.as_tensor(p_idx, device=Lcol.device)
+                Lc3[:, ti, :] = P.view(nb, nblk_q, nb)[:, pidx, :]
+        return Lrow, nrow_blk, Lcol, ncol_blk, lj0
+
+    def _update(self, K, opnd, c_from, c_to):
+        """A(I,J) -= L(I,K) L(J,K)^T on the local blocks with I > K and local column blocks
+        lj0 + c_from .. lj0 + c_to - 1 (tiles above the global diagonal are skipped)."""
+        if opnd is None:
+            return
+        Lrow, nrow_blk, Lcol, ncol_blk, lj0 = opnd
+        c_to = min(c_to, ncol_blk)
+        if c_to <= c_from:
+            return
+        nb, pr, pc = self.nb, self.pr, self.pc
+        li0 = _count_le(K, self.pi, pr)
+        m, n_all = nrow_blk * nb, ncol_blk * nb
+        ncols = (c_to - c_from) * nb
+        # the column operand is (n_all x nb) column-major; rows c_from*nb.. are its sub-block
+        self.ops.syrk_update(m, ncols, nb, Lrow, m, Lcol[c_from * nb:], n_all, self.A,
+                             li0 * nb + (lj0 + c_from) * nb * self.mloc, self.mloc,
+                             nb, pr, li0 * pr + self.pi, pc, (lj0 + c_from) * pc + self.pj)
+
+    def factor(self):
+        """Right-looking with one step of look-ahead: while the bulk of trailing update K runs,
+        panel K+1 (already updated) is factored, solved and on its way to the other ranks."""
         self.info = 0
         self.fail_t = torch.full((1,), self._BIG, dtype=torch.int64, device=self.info_t.device)
+        pieces, handles = self._panel_start(0)
+        for h in handles:
+            h.wait()
         for K in range(self.nbk):
-            kI, kJ = K % pr, K % pc
-            lj_K = K // pc
-            # (1) diagonal block
-            if (pi, pj) == (kI, kJ):
-                li_K = K // pr
-                blk = self.A2[lj_K * nb:(lj_K + 1) * nb, li_K * nb:(li_K + 1) * nb]
-                self.Lkk.view(nb, nb).copy_(blk)
-                ops.potrf(nb, self.Lkk, self.wbuf, self.info_t)
-                # LAPACK-style global index of the first failing minor, tracked on the device
-                cand = torch.where(self.info_t[:1] != 0, self.info_t[:1].to(torch.int64) + K * nb,
-                                   torch.full_like(self.fail_t, self._BIG))
-                self.fail_t = torch.minimum(self.fail_t, cand)
-                blk.copy_(self.Lkk.view(nb, nb))
-                self.work[K] = self.wbuf.clone()
-            # (2) panel solve on process column kJ
-            li0 = _count_le(K, pi, pr)            # first local block row with I > K
-            m_p = self.mloc - li0 * nb
-            if pj == kJ:
-                src = self.grank(kI, kJ)
-                dist.broadcast(self.Lkk, src=src, group=self.col_groups[kJ])
-                dist.broadcast(self.wbuf, src=src, group=self.col_groups[kJ])
-                if m_p > 0:
-                    ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, li0 * nb + lj_K * nb * self.mloc, self.mloc)
-            # (3) panel pieces of every process row -> everyone
-            pieces = []
-            for q in range(pr):
-                lq0 = _count_le(K, q, pr)
-                nblk_q = len(range(q, self.nbk, pr)) - lq0
-                P = ops.empty(nblk_q * nb * nb)
-                if nblk_q > 0:
-                    if (pi, pj) == (q, kJ):
-                        P.view(nb, nblk_q * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, lq0 * nb:])
-                    dist.broadcast(P, src=self.grank(q, kJ), group=self.group)
-                pieces.append((P, nblk_q, lq0))
-            # (4) operands of the local update
-            Lrow, nrow_blk, _ = pieces[pi]
-            lj0 = _count_le(K, pj, pc)            # first local block column with J > K
-            ncol_blk = len(self.cols) - lj0
-            if nrow_blk == 0 or ncol_blk == 0:
-                continue
-            Lcol = ops.empty(ncol_blk * nb * nb)
-            Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
-            for q in range(pr):
-                P, nblk_q, lq0 = pieces[q]
-                if nblk_q == 0:
-                    continue
-                t_idx, p_idx = [], []
-                for t in range(ncol_blk):
-                    J = self.cols[lj0 + t]
-                    if J % pr == q:
-                        t_idx.append(t)
-                        p_idx.append(J // pr - lq0)
-                if t_idx:
-                    ti = torch.as_tensor(t_idx, device=Lcol.device)
-                    pidx = torch.as_tensor(p_idx, device=Lcol.device)
-                    Lc3[:, ti, :] = P.view(nb, nblk_q, nb)[:, pidx, :]
-            # (5) A(I,J) -= L(I,K) L(J,K)^T on the local blocks with I, J > K
-            m, n = nrow_blk * nb, ncol_blk * nb
-            ops.syrk_update(m, n, nb, Lrow, m, Lcol, n, self.A, li0 * nb + lj0 * nb * self.mloc, self.mloc,
-                            nb, pr, li0 * pr + pi, pc, lj0 * pc + pj)
+            opnd = self._operands(K, pieces)
+            nxt = None
+            if K + 1 < self.nbk:
+                owns_next = (K + 1) % self.pc == self.pj   # block column K+1 is my first column > K
+                if owns_next:
+                    self._update(K, opnd, 0, 1)
+                nxt = self._panel_start(K + 1)
+                self._update(K, opnd, 1 if owns_next else 0, 1 << 30)
+                pieces, handles = nxt
+                for h in handles:
+                    h.wait()
+            else:
+                self._update(K, opnd, 0, 1 << 30)
         t = self.fail_t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         v = int(t.item())
