@@ -224,20 +224,23 @@ class DistFit:
             return None
         Lcol = ops.empty(ncol_blk * nb * nb)
         Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
+        # Column block t is global block J = J0 + pc t and sits in the piece of process row J % pr at
+        # position J // pr - lq0.  For a fixed q those t form an arithmetic progression, so the
+        # regrouping is a handful of strided device copies -- no index tensors, no host sync (a
+        # host-to-device index upload per step would serialise the look-ahead).
+        J0 = self.cols[lj0]
+        g = math.gcd(pc, pr)
+        period, pstep = pr // g, pc // g
         for q in range(pr):
             P, nblk_q, lq0 = pieces[q]
-            if nblk_q == 0:
+            if nblk_q == 0 or (q - J0) % g:
                 continue
-            t_idx, p_idx = [], []
-            for t in range(ncol_blk):
-                J = self.cols[lj0 + t]
-                if J % pr == q:
-                    t_idx.append(t)
-                    p_idx.append(J // pr - lq0)
-            if t_idx:
-                ti = torch.as_tensor(t_idx, device=Lcol.device)
-                pidx = torch.as_tensor(p_idx, device=Lcol.device)
-                Lc3[:, ti, :] = P.view(nb, nblk_q, nb)[:, pidx, :]
+            t_q = next(t for t in range(period) if (J0 + pc * t) % pr == q)
+            cnt = len(range(t_q, ncol_blk, period))
+            if cnt == 0:
+                continue
+            pos0 = (J0 + pc * t_q) // pr - lq0
+            Lc3[:, t_q::period, :] = P.view(nb, nblk_q, nb)[:, pos0:pos0 + (cnt - 1) * pstep + 1:pstep, :]
         return Lrow, nrow_blk, Lcol, ncol_blk, lj0
 
     def _update(self, K, opnd, c_from, c_to):
