@@ -220,6 +220,9 @@ int sgpr_probe_mfma_clock(int nacc, int waves_per_simd, int iters, double *out3)
 int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4);
 /* ablation bits for sgpr_probe_gemm (1 no refetch, 2 no barrier, 4 no fragment reads); 0 = normal */
 int sgpr_probe_gemm_debug(int bits);
+/* shader cycles per phase of one 128x128 leaf factorisation: load, diag block, panel rows,
+ * trailing update, write-back, inverse diag, inverse rows, final store */
+int sgpr_probe_leaf(double *out8);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ constexpr int PW = 16;             // panel width inside the leaf
 enum { LEAF_FACTOR = 0, LEAF_INVERT_ONLY = 1 };
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // A (nb x nb, lower, global) -> L in place (mode FACTOR) and inv(L) -> inv (LEAF x LEAF,
 // ld LEAF, zero-filled outside the nb x nb lower triangle).
@@ -39,51 +40,114 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 //   inverse: LAPACK dtrtri order (last panel first): X21 = -X22 L21 inv(L11) with one row per
 //            thread, inv(L11) by 16 lanes of wave 0.
 __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda, double *inv,
-                                                  int *dinfo, int goff, int mode)
+                                                  int *dinfo, int goff, int mode,
+                                                  unsigned long long *stamps)
 {
     __shared__ double s[LEAF * LLD];
     __shared__ double sInv[PW * (PW + 1)];
+    __shared__ double sT[(LEAF - PW) * (PW + 1)];   // T = X22 L21 strip of the inverse phase
+    __shared__ double sRl[PW];                      // 1 / L11(j,j) of the current panel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // diagnostic phase clock (stamps == nullptr in production): cycles per phase, summed over panels
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    auto mark = [&](int i) {
+        if (stamps) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[i] += t - tprev;
+            tprev = t;
+        }
+    };
 
-    for (int idx = tid; idx < LEAF * LEAF; idx += LT) {
-        const int i = idx % LEAF, c = idx / LEAF;
-        double v = (i == c) ? 1.0 : 0.0;               // identity padding beyond nb
-        if (i < nb && c < nb) v = (i >= c) ? A[(size_t)i + (size_t)c * lda] : 0.0;
-        s[c * LLD + i] = v;
+    if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
+        // full leaf: 32 independent 16-B loads per thread (the whole square is read, the strict
+        // upper triangle -- whatever it holds -- is replaced by zeros on the way into LDS)
+#pragma unroll 8
+        for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
+            const int idx = it * LT + tid;
+            const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
+            const double2_t v = *reinterpret_cast<const double2_t *>(A + (size_t)i + (size_t)c * lda);
+            s[c * LLD + i] = (i >= c) ? v.x : 0.0;
+            s[c * LLD + i + 1] = (i + 1 >= c) ? v.y : 0.0;
+        }
+    } else {
+        for (int idx = tid; idx < LEAF * LEAF; idx += LT) {
+            const int i = idx % LEAF, c = idx / LEAF;
+            double v = (i == c) ? 1.0 : 0.0;               // identity padding beyond nb
+            if (i < nb && c < nb) v = (i >= c) ? A[(size_t)i + (size_t)c * lda] : 0.0;
+            s[c * LLD + i] = v;
+        }
     }
     __syncthreads();
+    mark(0);
 
     if (mode == LEAF_FACTOR) {
-        for (int c0 = 0; c0 < LEAF; c0 += PW) {
-            // ---- (A) 16x16 diagonal block, wave 0: lane r holds row r
-            if (tid < 64) {
-                double a[PW];
+        const int wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+        // (A) 16x16 diagonal block at c0, one wave: lane r holds row r in registers; the pivot of
+        // column j comes from lane j by v_readlane, 1/sqrt by the hardware estimate + two Newton
+        // steps, the scaled column is published through a 16-double LDS strip and read back as
+        // broadcasts (15 independent reads instead of a chain of dependent cross-lane shuffles).
+        auto diag_factor = [&](int c0) {
+            double a[PW];
+#pragma unroll
+            for (int c = 0; c < PW; ++c)
+                a[c] = (lane < PW && c <= lane) ? s[(c0 + c) * LLD + c0 + lane] : 0.0;
+            bool bad = false;
+            int badj = 0;
+            auto pivot = [&](double v, int j, double &d, double &rl) {   // d = v on lane j; rl = 1/sqrt(d)
+                const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), j);
+                const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), j);
+                d = __hiloint2double((int)hi, (int)lo);
+                rl = __builtin_amdgcn_rsq(d);
+                rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
+                rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
+            };
+            double d, rl;
+            pivot(a[0], 0, d, rl);
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                if (!(d > 0.0) && !bad) { bad = true; badj = j; }
+                a[j] = (lane == j) ? d * rl : a[j] * rl;
+                if (lane < PW) sInv[1 + lane] = a[j];
+                if (lane == j) sRl[j] = rl;
+                // the next pivot needs only lane j+1's own values (a[j+1] - a[j]^2): its 1/sqrt chain
+                // runs while column j travels through LDS
+                double dn = 0.0, rn = 0.0;
+                if (j + 1 < PW) pivot(__builtin_fma(-a[j], a[j], a[j + 1]), j + 1, dn, rn);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int c = j + 1; c < PW; ++c) a[c] = __builtin_fma(-a[j], sInv[1 + c], a[c]);
+                __builtin_amdgcn_wave_barrier();
+                d = dn;
+                rl = rn;
+            }
+            if (bad && lane == 0 && *dinfo == 0) *dinfo = goff + c0 + badj + 1;
+            if (lane < PW) {
 #pragma unroll
                 for (int c = 0; c < PW; ++c)
-                    a[c] = (lane < PW && c <= lane) ? s[(c0 + c) * LLD + c0 + lane] : 0.0;
-                bool bad = false;
-                int badj = 0;
-#pragma unroll
-                for (int j = 0; j < PW; ++j) {
-                    const double d = __shfl(a[j], j, 64);
-                    if (!(d > 0.0) && !bad) { bad = true; badj = j; }
-                    const double l = sqrt(d);
-                    a[j] = (lane == j) ? l : a[j] / l;
-#pragma unroll
-                    for (int c = j + 1; c < PW; ++c) {
-                        const double lcj = __shfl(a[j], c, 64);
-                        a[c] = __builtin_fma(-a[j], lcj, a[c]);
-                    }
-                }
-                if (bad && tid == 0 && *dinfo == 0) *dinfo = goff + c0 + badj + 1;
-                if (lane < PW) {
-#pragma unroll
-                    for (int c = 0; c < PW; ++c)
-                        if (c <= lane) s[(c0 + c) * LLD + c0 + lane] = a[c];
-                }
+                    if (c <= lane) s[(c0 + c) * LLD + c0 + lane] = a[c];
             }
-            __syncthreads();
+        };
+        // (C) one 16x16 tile of the trailing update on the matrix cores: k = 16 = four
+        // v_mfma_f64_16x16x4_f64; both operands are "row contiguous, k strided" reads of the
+        // panel columns (A: lane&15 = i, B: lane&15 = j, lane>>4 = k).
+        auto update_tile = [&](int c0, int i0, int j0) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < PW / 4; ++kk) {
+                const double *col = s + (c0 + 4 * kk + l4) * LLD;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(col[i0 + l15], col[j0 + l15], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[(j0 + l15) * LLD + i0 + 4 * r + l4] -= acc[r];  // D(i,j): j = lane&15, i = 4r + lane>>4
+        };
+
+        if (wave == 0) diag_factor(0);
+        __syncthreads();
+        mark(1);
+        for (int c0 = 0; c0 < LEAF - PW; c0 += PW) {
             const int r0 = c0 + PW;
             const int rem = LEAF - r0;
             // ---- (B) panel rows: r := r L11^-T, one row per thread
@@ -97,116 +161,138 @@ __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda,
                     double acc = r[j];
 #pragma unroll
                     for (int k = 0; k < j; ++k) acc = __builtin_fma(-r[k], s[(c0 + k) * LLD + c0 + j], acc);
-                    r[j] = acc / s[(c0 + j) * LLD + c0 + j];
+                    r[j] = acc * sRl[j];
                 }
 #pragma unroll
                 for (int c = 0; c < PW; ++c) s[(c0 + c) * LLD + i] = r[c];
             }
             __syncthreads();
-            // ---- (C) trailing lower triangle -= L21 L21^T, 4x4 tiles
-            const int nt = rem / 4;
+            mark(2);
+            // ---- (C) trailing update, with the NEXT diagonal block factored underneath it: wave 0
+            // updates tile (0,0) first and goes straight on to (A) of the next panel while waves
+            // 1-3 update the other tiles.
+            const int nt = rem / 16;
             const int ntile = nt * (nt + 1) / 2;
-            for (int idx = tid; idx < ntile; idx += LT) {
-                int ti = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                while (ti * (ti + 1) / 2 > idx) --ti;
-                while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
-                const int tj = idx - ti * (ti + 1) / 2;
-                const int i0 = r0 + 4 * ti, j0 = r0 + 4 * tj;
-                double acc[4][4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll
-                for (int k = 0; k < PW; ++k) {
-                    const double *col = s + (c0 + k) * LLD;
-                    const double2_t a01 = *reinterpret_cast<const double2_t *>(col + i0);
-                    const double2_t a23 = *reinterpret_cast<const double2_t *>(col + i0 + 2);
-                    const double2_t b01 = *reinterpret_cast<const double2_t *>(col + j0);
-                    const double2_t b23 = *reinterpret_cast<const double2_t *>(col + j0 + 2);
-                    const double av[4] = {a01.x, a01.y, a23.x, a23.y};
-                    const double bv[4] = {b01.x, b01.y, b23.x, b23.y};
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_fma(av[a], bv[b], acc[a][b]);
-                }
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    double *col = s + (j0 + b) * LLD + i0;
-                    double2_t c01 = *reinterpret_cast<double2_t *>(col);
-                    double2_t c23 = *reinterpret_cast<double2_t *>(col + 2);
-                    c01.x -= acc[0][b]; c01.y -= acc[1][b]; c23.x -= acc[2][b]; c23.y -= acc[3][b];
-                    *reinterpret_cast<double2_t *>(col) = c01;
-                    *reinterpret_cast<double2_t *>(col + 2) = c23;
+            if (wave == 0) {
+                update_tile(c0, r0, r0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                diag_factor(r0);
+            } else {
+                for (int idx = wave; idx < ntile; idx += LT / 64 - 1) {
+                    int ti = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+                    while (ti * (ti + 1) / 2 > idx) --ti;
+                    while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
+                    const int tj = idx - ti * (ti + 1) / 2;
+                    update_tile(c0, r0 + 16 * ti, r0 + 16 * tj);
                 }
             }
             __syncthreads();
+            mark(3);
         }
-        for (int idx = tid; idx < nb * nb; idx += LT) {
-            const int i = idx % nb, c = idx / nb;
-            if (i >= c) A[(size_t)i + (size_t)c * lda] = s[c * LLD + i];
+        if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
+#pragma unroll 8
+            for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
+                const int idx = it * LT + tid;
+                const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
+                double *dst = A + (size_t)i + (size_t)c * lda;
+                if (i >= c) *reinterpret_cast<double2_t *>(dst) = double2_t{s[c * LLD + i], s[c * LLD + i + 1]};
+                else if (i + 1 >= c) dst[1] = s[c * LLD + i + 1];
+            }
+        } else {
+            for (int idx = tid; idx < nb * nb; idx += LT) {
+                const int i = idx % nb, c = idx / nb;
+                if (i >= c) A[(size_t)i + (size_t)c * lda] = s[c * LLD + i];
+            }
         }
         __syncthreads();
+        mark(4);
     }
 
-    // ---- inverse, last panel first; only the lower triangle of s is read
-    for (int c0 = LEAF - PW; c0 >= 0; c0 -= PW) {
-        // (a) inv(L11) by 16 lanes: column c solves L x = e_c
-        if (tid < PW) {
-            const int c = tid;
-            double x[PW];
+    // ---- inverse (LAPACK dtrtri order, last panel first); only the lower triangle of s is read.
+    // (I0) all eight 16x16 diagonal blocks are inverted at once, in place: 128 threads, one column
+    //      of one block each (x = solve L11 x = e_c), values held in registers across the barrier.
+    {
+        const int blk = tid >> 4, c = tid & 15, d0 = blk * PW;
+        double x[PW];
+        if (tid < 128) {
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 double acc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-                for (int k = 0; k < i; ++k) acc = __builtin_fma(-s[(c0 + k) * LLD + c0 + i], x[k], acc);
-                x[i] = acc / s[(c0 + i) * LLD + c0 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < PW; ++i) sInv[c * (PW + 1) + i] = x[i];
-        }
-        __syncthreads();
-        const int r0 = c0 + PW;
-        const int rem = LEAF - r0;
-        double out[PW];
-        if (tid < rem) {
-            // (b) T = X22 L21 (row i), then (c) X21 = -T inv(L11)
-            const int i = r0 + tid;
-            double t[PW];
-#pragma unroll
-            for (int c = 0; c < PW; ++c) t[c] = 0.0;
-            for (int k = r0; k < LEAF; ++k) {
-                const double xv = (k <= i) ? s[k * LLD + i] : 0.0;
-#pragma unroll
-                for (int c = 0; c < PW; ++c) t[c] = __builtin_fma(xv, s[(c0 + c) * LLD + k], t[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < PW; ++c) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = c; k < PW; ++k) acc = __builtin_fma(t[k], sInv[c * (PW + 1) + k], acc);
-                out[c] = -acc;
+                for (int k = 0; k < i; ++k) acc = __builtin_fma(-s[(d0 + k) * LLD + d0 + i], x[k], acc);
+                x[i] = acc / s[(d0 + i) * LLD + d0 + i];
             }
         }
         __syncthreads();
-        if (tid < rem) {
-            const int i = r0 + tid;
-#pragma unroll
-            for (int c = 0; c < PW; ++c) s[(c0 + c) * LLD + i] = out[c];
-        }
-        if (tid >= 64 && tid < 64 + PW) {  // another wave drops inv(L11) into the diagonal block
-            const int c = tid - 64;
+        if (tid < 128) {
 #pragma unroll
             for (int i = 0; i < PW; ++i)
-                if (i >= c) s[(c0 + c) * LLD + c0 + i] = sInv[c * (PW + 1) + i];
+                if (i >= c) s[(d0 + c) * LLD + d0 + i] = x[i];
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < LEAF * LEAF; idx += LT) {
-        const int i = idx % LEAF, c = idx / LEAF;
-        inv[idx] = (i >= c && i < nb && c < nb) ? s[c * LLD + i] : 0.0;
+    mark(5);
+    // (I1) per panel: T = X22 L21 in 4x2 register tiles (224 threads), through the sT strip, then
+    //      X21 = -T inv(L11) with inv(L11) read from the (already inverted) diagonal block.
+    for (int c0 = LEAF - 2 * PW; c0 >= 0; c0 -= PW) {
+        const int r0 = c0 + PW;
+        const int rem = LEAF - r0;            // rows below the panel's diagonal block, multiple of 16
+        const int nt = rem / 16;
+        const int wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+        // T = X22 L21: row tile `it` needs k = r0 .. its own last row (X22 lower triangular; the
+        // strict upper part of its diagonal block is masked to zero)
+        for (int idx = wave; idx < nt; idx += LT / 64) {
+            const int it = nt - 1 - idx;                      // heaviest tiles first
+            const int i = r0 + 16 * it + l15;
+            // 16 k per trip: the eight LDS reads of a trip are issued together and two accumulator
+            // chains alternate (a one-step loop is a chain of LDS + MFMA latencies)
+            double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            for (int kb = r0; kb < r0 + 16 * (it + 1); kb += 16) {
+                double xa[4], lb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = kb + 4 * u + l4;
+                    xa[u] = (k <= i) ? s[k * LLD + i] : 0.0;
+                    lb[u] = s[(c0 + l15) * LLD + k];
+                }
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], lb[0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], lb[1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], lb[2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], lb[3], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sT[(16 * it + 4 * r + l4) * (PW + 1) + l15] = acc0[r] + acc1[r];
+        }
+        __syncthreads();
+        mark(6);
+        // X21 = -T inv(L11): inv(L11) sits in the (already inverted) diagonal block, lower triangular
+        for (int it = wave; it < nt; it += LT / 64) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < PW / 4; ++kk) {
+                const int k = 4 * kk + l4;
+                const double ta = sT[(16 * it + l15) * (PW + 1) + k];
+                const double xb = (k >= l15) ? s[(c0 + l15) * LLD + c0 + k] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, xb, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[(c0 + l15) * LLD + r0 + 16 * it + 4 * r + l4] = -acc[r];
+        }
+        __syncthreads();
+        mark(5);
     }
+#pragma unroll 8
+    for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
+        const int idx = it * LT + tid;
+        const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
+        const double v0 = (i >= c && i < nb && c < nb) ? s[c * LLD + i] : 0.0;
+        const double v1 = (i + 1 >= c && i + 1 < nb && c < nb) ? s[c * LLD + i + 1] : 0.0;
+        *reinterpret_cast<double2_t *>(inv + (size_t)i + (size_t)c * LEAF) = double2_t{v0, v1};
+    }
+    mark(7);
+    if (stamps && tid == 0)
+        for (int i = 0; i < 8; ++i) stamps[i] = ph[i];
 }
 
 // b(nb) := inv(L) b  or  inv(L)^T b   (inv: LEAF x LEAF lower, zero upper).
@@ -273,7 +359,8 @@ int potrf_rec(int n, double *A, size_t lda, int off, const Ctx &c)
 {
     if (n <= LEAF) {
         hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(LT), 0, c.st, n, A, lda,
-                           c.inv + (size_t)(off / LEAF) * LEAF * LEAF, c.dinfo, off, (int)LEAF_FACTOR);
+                           c.inv + (size_t)(off / LEAF) * LEAF * LEAF, c.dinfo, off, (int)LEAF_FACTOR,
+                           (unsigned long long *)nullptr);
         SGPR_CHECK_LAUNCH();
         return 0;
     }
@@ -326,7 +413,7 @@ int leaves_invert_only(int n, double *L, size_t ldl, const Ctx &c)
         const int nb = n - off < LEAF ? n - off : LEAF;
         hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(LT), 0, c.st, nb, L + off + (size_t)off * ldl, ldl,
                            c.inv + (size_t)(off / LEAF) * LEAF * LEAF, c.dinfo, off,
-                           (int)LEAF_INVERT_ONLY);
+                           (int)LEAF_INVERT_ONLY, (unsigned long long *)nullptr);
         SGPR_CHECK_LAUNCH();
     }
     return 0;
@@ -374,6 +461,15 @@ int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int tr
     if (n <= 0) return 0;
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
     return trans ? trsv_t_rec(n, L, ldl, b, 0, c) : trsv_n_rec(n, L, ldl, b, 0, c);
+}
+
+// diagnostic: one leaf factorisation with per-phase cycle counts (load, diag, panel, update,
+// write-back, inv diag, inv rows, tail)
+int leaf_probe(double *A, size_t lda, double *inv, int *dinfo, unsigned long long *stamps, hipStream_t st)
+{
+    hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(LT), 0, st, (int)LEAF, A, lda, inv, dinfo, 0, (int)LEAF_FACTOR, stamps);
+    SGPR_CHECK_LAUNCH();
+    return 0;
 }
 
 // leaf inverses of an existing factor (for solves against an L that was not produced by potrf())

@@ -77,6 +77,7 @@ int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, c
              hipStream_t st);
 int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st);
 int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st);
+int leaf_probe(double *A, size_t lda, double *inv, int *dinfo, unsigned long long *stamps, hipStream_t st);
 int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st);
 
 // ---- blas_small.hip

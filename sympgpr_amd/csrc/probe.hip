@@ -208,3 +208,31 @@ extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     return 0;
 }
+
+// Diagnostic: phase cycle counts of one 128x128 leaf factorisation (out8, shader cycles)
+extern "C" int sgpr_probe_leaf(double *out8)
+{
+    const int n = LEAF;
+    std::vector<double> h((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) h[i + (size_t)j * n] = (i == j) ? 4.0 + 0.01 * i : 1.0 / (1.0 + i + j);
+    double *A = nullptr, *inv = nullptr;
+    int *info = nullptr;
+    unsigned long long *st = nullptr;
+    SGPR_HIP(hipMalloc((void **)&A, sizeof(double) * n * n));
+    SGPR_HIP(hipMalloc((void **)&inv, sizeof(double) * n * n));
+    SGPR_HIP(hipMalloc((void **)&info, 16));
+    SGPR_HIP(hipMalloc((void **)&st, 64));
+    SGPR_HIP(hipMemset(info, 0, 16));
+    for (int rep = 0; rep < 2; ++rep) {
+        SGPR_HIP(hipMemcpy(A, h.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
+        int rc = leaf_probe(A, n, inv, info, st, nullptr);
+        if (rc) return rc;
+        SGPR_HIP(hipDeviceSynchronize());
+    }
+    unsigned long long hs[8];
+    SGPR_HIP(hipMemcpy(hs, st, 64, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; ++i) out8[i] = (double)hs[i];
+    (void)hipFree(A); (void)hipFree(inv); (void)hipFree(info); (void)hipFree(st);
+    return 0;
+}
