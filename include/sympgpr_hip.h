@@ -208,6 +208,9 @@ int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, dou
  * 128x128-tile kernel, [6..7] flop / ms of the single largest launch. */
 int sgpr_profile_begin(void);
 int sgpr_profile_end(double *out8);
+/* per-launch records of the window closed by the last sgpr_profile_end: 6 doubles each
+ * (m, n, k, lower, big-tile flag, ms); returns the number of records available */
+int sgpr_profile_launches(double *buf, int max_records);
 
 /* Roofline calibration probes (measurement aids): a register-only fp64 MFMA issue loop with
  * `waves_per_simd` waves on every SIMD, and a streaming 16-B/lane write of `bytes` bytes. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sgpr_probe_hbm_write": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "sgpr_profile_begin": (C.c_int, []),
     "sgpr_profile_end": (C.c_int, [_dp]),
+    "sgpr_profile_launches": (C.c_int, [_dp, C.c_int]),
     "sgpr_gemm_nt_bc_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t,
                                       C.c_double, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sgpr_trsv_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int, _vp]),

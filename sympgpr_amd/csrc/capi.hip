@@ -697,6 +697,8 @@ int sgpr_profile_end(double *out8)
     return gemm_profile_end(out8);
 }
 
+int sgpr_profile_launches(double *buf, int max_records) { return gemm_profile_launches(buf, max_records); }
+
 int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b, void *stream)
 {
     int rc = need_device();

@@ -68,6 +68,7 @@ void gemm_profile_begin();
 void gemm_set_stamps(unsigned long long *dev_buf);
 void gemm_set_debug(int bits);
 int gemm_profile_end(double *out8);
+int gemm_profile_launches(double *buf, int max_records);
 
 // ---- chol.hip : leaf factor / leaf inverse / recursion / solves
 constexpr int LEAF = 128;  // order of the diagonal block factored in LDS by one workgroup

@@ -28,7 +28,7 @@ namespace sgpr {
 namespace {
 
 // optional per-launch HIP-event timing (bench.py's roofline leg); off by default
-struct ProfRec { hipEvent_t a, b; double flop; int big; };
+struct ProfRec { hipEvent_t a, b; double flop; int big; int m, n, k, lower; };
 struct Prof { bool on = false; std::vector<ProfRec> recs; };
 Prof g_prof;
 int g_dbg = 0;
@@ -497,7 +497,7 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
 // (<= 256 VGPRs): one 512-thread workgroup per CU (256x128), or two independent 256-thread
 // workgroups per CU (128x128) whose barriers do not line up.
 template <int BM, int BN>
-__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_nt_kernel(const GemmArgs g)
+__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (BM >= 128 ? 2 : 1)) void gemm_nt_kernel(const GemmArgs g)
 {
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
     __shared__ double smem[2 * BK * (LDA_S + LDB_S)];
@@ -510,9 +510,11 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), 2) void gemm_nt_kernel(
     }
     const bool aligned = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
     const bool fast = aligned && (row0 + BM <= g.m) && (col0 + BN <= g.n) && (g.k % BK == 0);
-    if (fast && !(g.dbg & 16)) gemm_body_dma<BM, BN>(g, smem, tile_r, tile_c);
-    else if (fast)             gemm_body<BM, BN, true>(g, smem, tile_r, tile_c);
-    else                       gemm_body<BM, BN, false>(g, smem, tile_r, tile_c);
+    if constexpr (BM % 128 == 0) {
+        if (fast && !(g.dbg & 16)) { gemm_body_dma<BM, BN>(g, smem, tile_r, tile_c); return; }
+    }
+    if (fast) gemm_body<BM, BN, true>(g, smem, tile_r, tile_c);
+    else      gemm_body<BM, BN, false>(g, smem, tile_r, tile_c);
 }
 
 }  // namespace
@@ -572,6 +574,7 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
             }
         }
         rec.flop = 2.0 * k * elems;
+        rec.m = m; rec.n = n; rec.k = k; rec.lower = lower;
         SGPR_HIP(hipEventCreate(&rec.a));
         SGPR_HIP(hipEventCreate(&rec.b));
         SGPR_HIP(hipEventRecord(rec.a, st));
@@ -585,7 +588,13 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
     // aspect).  So: 256x128 whenever it yields >= 256 workgroups, 128x128 below.
     // SGPR_GEMM_TILE=small forces the 128x128 shape (A/B experiments).
     static const bool prefer_big = [] { const char *e = getenv("SGPR_GEMM_TILE"); return !(e && e[0] == 's'); }();
-    if (prefer_big && !(g_dbg & 8) && (big >= 256 || (m >= 256 && n == 128))) {
+    if (n <= 128 && m < 65536 && !(g_dbg & 8)) {
+        // one column tile (the in-place panel solve against an inverted leaf, k = n <= 128): a
+        // latency problem, not a throughput one -- 64-row tiles quadruple the workgroup count and
+        // halve the per-workgroup critical path (two waves, register-staged operands)
+        const dim3 grid(set_map(64, 128));
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 128>), grid, dim3(128), 0, st, g);
+    } else if (prefer_big && !(g_dbg & 8) && (big >= 256 || (m >= 256 && n == 128))) {
         const dim3 grid(set_map(256, 128));
         hipLaunchKernelGGL((gemm_nt_kernel<256, 128>), grid, dim3(512), 0, st, g);
         rec.big = 1;
@@ -612,9 +621,21 @@ void gemm_profile_begin()
 }
 
 // out[0..2]: big-tile launches / flop / ms; out[3..5]: small-tile; out[6..7]: largest launch flop / ms
+// per-launch records of the last profile window: 6 doubles each (m, n, k, lower, big, ms)
+static std::vector<double> g_last_launches;
+int gemm_profile_launches(double *buf, int max_records)
+{
+    const int n = (int)(g_last_launches.size() / 6);
+    if (buf)
+        for (int i = 0; i < n && i < max_records; ++i)
+            for (int j = 0; j < 6; ++j) buf[6 * i + j] = g_last_launches[6 * i + j];
+    return n;
+}
+
 int gemm_profile_end(double *out)
 {
     g_prof.on = false;
+    g_last_launches.clear();
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
     for (auto &r : g_prof.recs) {
         SGPR_HIP(hipEventSynchronize(r.b));
@@ -623,6 +644,8 @@ int gemm_profile_end(double *out)
         const int o = r.big ? 0 : 3;
         out[o] += 1.0; out[o + 1] += r.flop; out[o + 2] += ms;
         if (r.flop > out[6]) { out[6] = r.flop; out[7] = ms; }
+        for (double v : {(double)r.m, (double)r.n, (double)r.k, (double)r.lower, (double)r.big, (double)ms})
+            g_last_launches.push_back(v);
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
