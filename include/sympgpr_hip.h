@@ -126,6 +126,11 @@ int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs);
  * out_p[k] = Kstar(1,:).alpha, out_q[k] = Kstar(2,:).alpha */
 int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P, double *out_p,
                           double *out_q);
+/* Ky^-1 (n x n, full symmetric, host buffer) from the cached factor: what the drivers compute with
+ * scipy.linalg.inv(K + sig2n I) (01_pendulum/implicit/main.py:161) and hand to calcP / calcQ /
+ * applymap as `Kyinv`.  W = L^-T by a panel solve on the identity, Ky^-1 = W W^T by the SYRK
+ * kernel; two n x n scratch matrices on the device. */
+int sgpr_fit_inverse(sgpr_fit_t f, double *Kyinv, size_t ld);
 /* gradient of the nll with respect to (lx, ly) on a solved fit: what nll_grad / nll_grad_reg
  * return as nlp_grad (functions/func.py:132-162) */
 int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2);
@@ -221,7 +226,7 @@ int sgpr_probe_mfma_clock(int nacc, int waves_per_simd, int iters, double *out3)
 /* one synthetic C -= A B^T with per-workgroup stamps: TFLOP/s, median k-loop cycles per
  * workgroup, median shader clock (GHz), k-steps per workgroup */
 int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4);
-/* ablation bits for sgpr_probe_gemm (1 no refetch, 2 no barrier, 4 no fragment reads); 0 = normal */
+/* probe switches for sgpr_probe_gemm: 8 = 128x128 tile shape, 16 = register-staged body; 0 = normal */
 int sgpr_probe_gemm_debug(int bits);
 /* shader cycles per phase of one 128x128 leaf factorisation: load, diag block, panel rows,
  * trailing update, write-back, inverse diag, inverse rows, final store */

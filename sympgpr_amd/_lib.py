@@ -56,6 +56,7 @@ SIGNATURES = {
     "sgpr_fit_solve_rhs": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
     "sgpr_fit_predict_rows": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "sgpr_fit_nll_grad": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_inverse": (C.c_int, [_vp, _dp, C.c_size_t]),
     "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
     "sgpr_fit_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
     "sgpr_fit_destroy": (C.c_int, [_vp]),

@@ -490,6 +490,31 @@ int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P,
     return 0;
 }
 
+int sgpr_fit_inverse(sgpr_fit_t f, double *Kyinv, size_t ld)
+{
+    if (!f || !Kyinv || ld < (size_t)f->n) { set_error("fit_inverse: bad arguments"); return SGPR_E_ARG; }
+    if (!f->factored) { set_error("fit_inverse: no valid factor"); return SGPR_E_STATE; }
+    const size_t n = (size_t)f->n;
+    DevBuf W, R;
+    int rc;
+    if ((rc = W.alloc(n * n * sizeof(double))) || (rc = R.alloc(n * n * sizeof(double)))) return rc;
+    double *w = W.as<double>(), *r = R.as<double>();
+    SGPR_HIP(hipMemsetAsync(w, 0, n * n * sizeof(double), f->st));
+    {   // identity: one strided memset-like copy of ones onto the diagonal
+        std::vector<double> ones(n, 1.0);
+        SGPR_HIP(hipMemcpy2DAsync(w, (n + 1) * sizeof(double), ones.data(), sizeof(double), sizeof(double), n,
+                                  hipMemcpyHostToDevice, f->st));
+        SGPR_HIP(hipStreamSynchronize(f->st));
+    }
+    if ((rc = trsm_rlt(f->n, f->n, f->dA, n, w, n, f->work, f->st))) return rc;            // W = L^-T
+    if ((rc = gemm_nt(f->n, f->n, f->n, 1.0, w, n, w, n, 0.0, r, n, 1, 0, f->st))) return rc;  // lower(W W^T)
+    if ((rc = sym_fill_upper(f->n, r, n, f->st))) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(Kyinv, ld * sizeof(double), r, n * sizeof(double), n * sizeof(double), n,
+                              hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    return 0;
+}
+
 /* d nll / d(lx, ly) as nll_grad / nll_grad_reg compute it (functions/func.py:132-162):
  *   grad_i = -1/2 alpha^T dK_i alpha + 1/2 tr(Ky^-1 dK_i).
  * The reference forms Ky^-1 explicitly; here tr(Ky^-1 dK) = tr(L^-1 dK L^-T): W = dK, W := W L^-T

@@ -58,8 +58,7 @@ struct GemmArgs {
     //   (last_row / lblk) * lpr + lpi >= (first_col / lblk) * lpc + lpj
     // single GPU: lblk = 1, lpr = lpc = 1, lpi = diag_off, lpj = 0  (row + diag_off >= col)
     int lblk, lpr, lpi, lpc, lpj;
-    int dbg;  // ablation bits for the probe only (results are wrong when set): 1 = no operand
-              // refetch after tile 0, 2 = no in-loop barrier, 4 = no fragment reads in the loop
+    int dbg;  // probe switches: 8 = force the 128x128 tile shape, 16 = force the register-staged body
 };
 
 // Workgroup -> tile map.  The dispatcher deals consecutive workgroup ids round-robin over the 8
@@ -209,7 +208,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
     //                   next step starts with its operands already in registers.
     double fa[2][4], fb[2][4];
     auto load_frags = [&](int buf, int kk, int set) {
-        if (g.dbg & 4) return;
         const double *sA = sA0 + buf * BK * LDA_S + wm * 64 + l15 + (kk * 4 + l4) * LDA_S;
         const double *sB = sB0 + buf * BK * LDB_S + wn * 64 + l15 + (kk * 4 + l4) * LDB_S;
 #pragma unroll
@@ -235,7 +233,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
     }
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        const bool more = (t + 1 < T) && !(g.dbg & 1);
+        const bool more = t + 1 < T;
         if (more) fetch(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         // kk = 0
@@ -267,8 +265,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
         // kk = 3
         mfma_rows(1, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (!(g.dbg & 2)) __syncthreads();
-        if (more || (g.dbg & 1)) load_frags(cur ^ 1, 0, 0);
+        __syncthreads();
+        if (more) load_frags(cur ^ 1, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         mfma_rows(1, 2, 4);
         __builtin_amdgcn_sched_barrier(0);

@@ -80,6 +80,12 @@ class SympFit:
         L.check(self._lib.sgpr_fit_nll_grad(self._h, L.dptr(g)), "sgpr_fit_nll_grad")
         return g
 
+    def inverse(self):
+        """Ky^-1 as an F-ordered host array (the drivers' scipy.linalg.inv(K + sig2n I))."""
+        A = np.empty((self.n, self.n), order="F")
+        L.check(self._lib.sgpr_fit_inverse(self._h, L.dptr(A), self.n), "sgpr_fit_inverse")
+        return A
+
     def ldiag(self):
         out = np.empty(self.n)
         L.check(self._lib.sgpr_fit_ldiag(self._h, L.dptr(out)), "sgpr_fit_ldiag")

@@ -511,3 +511,62 @@ def test_nll_grad_vs_oracle(oracle, fam, Np):
         np.testing.assert_allclose(gr, gr_o, rtol=1e-9)
     finally:
         func.set_family("A")
+
+
+# ---------------------------------------------------------------- inverse, edge cases
+@pytest.mark.parametrize("N", [20, 300, 1000])
+def test_fit_inverse(oracle, N):
+    """Kyinv = scipy.linalg.inv(K + sig2n I) as the drivers form it (01_pendulum/implicit/main.py:161)."""
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(N)
+    q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+    l = 2.0 * np.sqrt(12 * np.pi / N)
+    hyp, s2 = [l, l, 1.0], 1e-2 / l**2
+    Ky = oracle.build_K("A", q, P, q, P, hyp) + s2 * np.eye(2 * N)
+    with SympFit("A", q, P, z, hyp, s2) as f:
+        f.run()
+        Ki = f.inverse()
+        a = f.alpha()
+    assert np.abs(Ki - Ki.T).max() == 0.0
+    assert np.abs(Ki @ Ky - np.eye(2 * N)).max() < 1e-9
+    assert np.linalg.norm(Ki @ z - a) / np.linalg.norm(a) < 1e-10
+
+
+def test_edge_shapes(ops, oracle):
+    """empty and one-point inputs (the reference builds a 2 x 2N0 K* row block with N = 1 on every
+    prediction, sympgpr.f90:82-84)."""
+    from sympgpr_amd.fit import SympFit
+    K = np.empty((0, 0), order="F")
+    ops.build_k([], [], [], [], [0.5, 2.0, 0.4], K)
+    K = np.empty((0, 8), order="F")
+    ops.build_k([], [], [1.0, 2, 3, 4], [0.0, 1, 2, 3], [0.5, 2.0, 0.4], K)
+    K = np.full((2, 6), np.nan, order="F")
+    ops.build_k([1.5], [0.2], [1.0, 2.0, 3.0], [0.0, 3.0, 2.0], [0.5, 2.0, 0.4], K)
+    assert gram_close(K, oracle.build_K("A", [1.5], [0.2], [1.0, 2.0, 3.0], [0.0, 3.0, 2.0], [0.5, 2.0, 0.4]))
+    with SympFit("A", [1.0], [0.5], [0.3, -0.2], [0.5, 2.0, 0.4], 1e-3) as f:   # one training point: n = 2
+        a = f.run().alpha()
+    a_o, _, _ = oracle.fit("A", [1.0], [0.5], [0.3, -0.2], [0.5, 2.0, 0.4], 1e-3)
+    np.testing.assert_allclose(a, a_o, rtol=1e-13)
+    assert ops.cholesky(np.zeros((0, 0))).shape == (0, 0)
+    with pytest.raises(ValueError):
+        ops.cholesky(np.ones((2, 3)))
+
+
+def test_fit_matrix_roundtrip(oracle):
+    """get_matrix after build returns the full symmetric Ky (also from a lower-only build),
+    after factor the SciPy-shaped L."""
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(2)
+    N = 150
+    q, P = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N)
+    hyp, s2 = [0.4, 0.6, 1.2], 5e-2
+    Ko = oracle.build_K("A", q, P, q, P, hyp) + s2 * np.eye(2 * N)
+    for lower_only in (True, False):
+        with SympFit("A", q, P, None, hyp, s2, lower_only=lower_only) as f:
+            f.build()
+            assert gram_close(f.matrix(), Ko)
+            f.factor()
+            Lh = f.matrix()
+            assert np.all(np.triu(Lh, 1) == 0) and np.abs(Lh @ Lh.T - Ko).max() < 1e-12
+            X = f.solve_rhs(np.eye(2 * N)[:, :3])
+            assert np.abs(Ko @ X - np.eye(2 * N)[:, :3]).max() < 1e-10
