@@ -256,6 +256,12 @@ int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, i
     SGPR_HIP(hipMemcpy2DAsync(dB.p, ld * sizeof(double), B, ldb * sizeof(double), ld * sizeof(double), nrhs,
                               hipMemcpyHostToDevice, st));
     if ((rc = leaf_inverses(n, dL.as<double>(), ld, dW.p, nullptr, st))) return rc;
+    if (nrhs >= 8) {  // many right-hand sides: GEMM-shaped solves on the matrix cores
+        DevBuf dS;
+        if ((rc = dS.alloc(ld * nrhs * sizeof(double)))) return rc;
+        if ((rc = potrs_mat(n, dL.as<double>(), ld, dW.p, dB.as<double>(), ld, nrhs, dS.as<double>(), st))) return rc;
+        SGPR_HIP(hipStreamSynchronize(st));
+    } else
     for (int r = 0; r < nrhs; ++r)
         if ((rc = potrs_vec(n, dL.as<double>(), ld, dW.p, dB.as<double>() + (size_t)r * ld, st))) return rc;
     SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, ld * sizeof(double), ld * sizeof(double), nrhs,
@@ -457,6 +463,12 @@ int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs)
     if (rc) return rc;
     SGPR_HIP(hipMemcpy2DAsync(dB.p, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs,
                               hipMemcpyHostToDevice, f->st));
+    if (nrhs >= 8) {
+        DevBuf dS;
+        if ((rc = dS.alloc(n * nrhs * sizeof(double)))) return rc;
+        if ((rc = potrs_mat(f->n, f->dA, n, f->work, dB.as<double>(), n, nrhs, dS.as<double>(), f->st))) return rc;
+        SGPR_HIP(hipStreamSynchronize(f->st));
+    } else
     for (int r = 0; r < nrhs; ++r)
         if ((rc = potrs_vec(f->n, f->dA, n, f->work, dB.as<double>() + (size_t)r * n, f->st))) return rc;
     SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, n * sizeof(double), n * sizeof(double), nrhs,

@@ -355,6 +355,21 @@ int trsm_rec(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, i
     return trsm_rec(m, n2, L + n1 + (size_t)n1 * ldl, ldl, B + (size_t)n1 * ldb, ldb, off + n1, c);
 }
 
+// B (m x n) := B L^-1 (L lower, its leaf inverses in the workspace): the backward half of a
+// multi-right-hand-side solve with the right-hand sides stored as ROWS.
+//   X2 = B2 L22^-1 ;  B1 -= X2 L21 ("NN" product) ;  X1 = B1 L11^-1
+int trsm_rl_rec(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, int off, const Ctx &c)
+{
+    if (n <= LEAF)  // B := B inv(L), in place (one column tile, workgroups own full rows)
+        return gemm_nn(m, n, n, 1.0, B, ldb, c.inv + (size_t)(off / LEAF) * LEAF * LEAF, LEAF, 0.0, B, ldb, c.st);
+    const int n1 = split(n), n2 = n - n1;
+    int rc = trsm_rl_rec(m, n2, L + n1 + (size_t)n1 * ldl, ldl, B + (size_t)n1 * ldb, ldb, off + n1, c);
+    if (rc) return rc;
+    rc = gemm_nn(m, n1, n2, -1.0, B + (size_t)n1 * ldb, ldb, L + n1, ldl, 1.0, B, ldb, c.st);
+    if (rc) return rc;
+    return trsm_rl_rec(m, n1, L, ldl, B, ldb, off, c);
+}
+
 int potrf_rec(int n, double *A, size_t lda, int off, const Ctx &c)
 {
     if (n <= LEAF) {
@@ -453,6 +468,26 @@ int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, h
     int rc = trsv_n_rec(n, L, ldl, b, 0, c);
     if (rc) return rc;
     return trsv_t_rec(n, L, ldl, b, 0, c);
+}
+
+int trsm_rl(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work, hipStream_t st)
+{
+    if (m <= 0 || n <= 0) return 0;
+    Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
+    return trsm_rl_rec(m, n, L, ldl, B, ldb, 0, c);
+}
+
+// B (n x nrhs) := L^-T L^-1 B through the MFMA kernel: the right-hand sides are transposed into
+// rows (scratch, nrhs x n), X^T = B^T L^-T (forward) then X^T L^-1 (backward), transposed back.
+int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, size_t ldb, int nrhs,
+              double *scratch, hipStream_t st)
+{
+    if (n <= 0 || nrhs <= 0) return 0;
+    int rc = transpose(n, nrhs, B, ldb, scratch, (size_t)nrhs, st);
+    if (rc) return rc;
+    if ((rc = trsm_rlt(nrhs, n, L, ldl, scratch, (size_t)nrhs, work, st))) return rc;
+    if ((rc = trsm_rl(nrhs, n, L, ldl, scratch, (size_t)nrhs, work, st))) return rc;
+    return transpose(nrhs, n, scratch, (size_t)nrhs, B, ldb, st);
 }
 
 // one-sided solve: b := L^-1 b (trans = 0) or L^-T b (trans = 1)

@@ -64,6 +64,8 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
 int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
                size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc5,
                hipStream_t st);
+int gemm_nn(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
+            double beta, double *C, size_t ldc, hipStream_t st);
 void gemm_profile_begin();
 void gemm_set_stamps(unsigned long long *dev_buf);
 void gemm_set_debug(int bits);
@@ -77,6 +79,9 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
              hipStream_t st);
 int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st);
+int trsm_rl(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work, hipStream_t st);  // B := B L^-1
+int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, size_t ldb, int nrhs, double *scratch,
+              hipStream_t st);  // B (n x nrhs) := L^-T L^-1 B; scratch: nrhs x n doubles
 int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st);
 int leaf_probe(double *A, size_t lda, double *inv, int *dinfo, unsigned long long *stamps, hipStream_t st);
 int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st);

@@ -32,6 +32,7 @@ struct ProfRec { hipEvent_t a, b; double flop; int big; int m, n, k, lower; };
 struct Prof { bool on = false; std::vector<ProfRec> recs; };
 Prof g_prof;
 int g_dbg = 0;
+int g_transb_next = 0;  // set by gemm_nn around its call
 unsigned long long *g_stamps = nullptr;  // set by gemm_set_stamps (diagnostics only)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -51,6 +52,7 @@ struct GemmArgs {
     size_t ldc;
     int lower;
     long diag_off;
+    int transb;                  // B is (k x n) column-major ("NN" product) instead of (n x k)
     unsigned long long *stamps;  // diagnostic: per-workgroup shader-clock / real-time stamps, or null
     // tile -> workgroup map (see tile_of): super-tiles of SR x SC tiles, one per XCD at a time
     int tiles_m, tiles_n, n_sr, n_sc, n_super, tri;
@@ -150,6 +152,43 @@ __device__ __forceinline__ void store_tile(double *S, int tid,
     }
 }
 
+// "NN" form: the n-side operand is given as B (k x n) column-major, i.e. k is the contiguous index.
+// A thread loads two consecutive k of one column (16 B) and scatters them into the [k][col] image.
+template <int BR, int THREADS, bool FAST>
+__device__ __forceinline__ void load_tile_t(const double *P, size_t ld, int col0, int k0, int cols,
+                                            int kmax, int tid, double2_t (&reg)[BR * BK / (2 * THREADS)])
+{
+    constexpr int PASSES = BR * BK / (2 * THREADS);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int e = p * THREADS + tid;
+        const int kp = 2 * (e % (BK / 2));
+        const int r = e / (BK / 2);
+        if constexpr (FAST) {
+            reg[p] = *reinterpret_cast<const double2_t *>(P + (size_t)(k0 + kp) + (size_t)(col0 + r) * ld);
+        } else {
+            const int cc = min(col0 + r, cols - 1);
+            const int ka = min(k0 + kp, kmax - 1), kb = min(k0 + kp + 1, kmax - 1);
+            const double *col = P + (size_t)cc * ld;
+            const double a = col[ka], b = col[kb];
+            const bool cok = (col0 + r) < cols;
+            double2_t v;
+            v.x = (cok && (k0 + kp) < kmax) ? a : 0.0;
+            v.y = (cok && (k0 + kp + 1) < kmax) ? b : 0.0;
+            reg[p] = v;
+        }
+    }
+}
+template <int BR, int THREADS>
+__device__ __forceinline__ void store_pass_t(double *S, int tid, const double2_t &v, int p)
+{
+    const int e = p * THREADS + tid;
+    const int kp = 2 * (e % (BK / 2));
+    const int r = e / (BK / 2);
+    S[kp * (BR + PAD) + r] = v.x;
+    S[(kp + 1) * (BR + PAD) + r] = v.y;
+}
+
 // one staging pass (a quarter / half of a tile) -> LDS; lets the k-loop slot the writes between MFMAs
 template <int BR, int THREADS>
 __device__ __forceinline__ void store_pass(double *S, int tid, const double2_t &v, int p)
@@ -160,7 +199,7 @@ __device__ __forceinline__ void store_pass(double *S, int tid, const double2_t &
     *reinterpret_cast<double2_t *>(S + kc * (BR + PAD) + r) = v;
 }
 
-template <int BM, int BN, bool FAST>
+template <int BM, int BN, bool FAST, bool TRANSB = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int tile_r, int tile_c)
 {
     constexpr int WGM = BM / 64, WGN = BN / 64;
@@ -196,7 +235,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
     auto fetch = [&](int t) {
         const int k0 = t * BK;
         load_tile<BM, THREADS, FAST>(g.A, g.lda, row0, k0, g.m, g.k, tid, ra);
-        load_tile<BN, THREADS, FAST>(g.B, g.ldb, col0, k0, g.n, g.k, tid, rb);
+        if constexpr (TRANSB) load_tile_t<BN, THREADS, FAST>(g.B, g.ldb, col0, k0, g.n, g.k, tid, rb);
+        else                  load_tile<BN, THREADS, FAST>(g.B, g.ldb, col0, k0, g.n, g.k, tid, rb);
+    };
+    auto store_b = [&](double *S, int p) {
+        if constexpr (TRANSB) store_pass_t<BN, THREADS>(S, tid, rb[p], p);
+        else                  store_pass<BN, THREADS>(S, tid, rb[p], p);
     };
 
     // Software pipeline (one barrier per k-step, placed where every wave still has MFMAs queued):
@@ -227,7 +271,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
     if (T > 0) {
         fetch(0);
         store_tile<BM, THREADS>(sA0, tid, ra);
-        store_tile<BN, THREADS>(sB0, tid, rb);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) store_b(sB0, p);
         __syncthreads();
         load_frags(0, 0, 0);
     }
@@ -258,7 +303,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
 #pragma unroll
                 for (int p = i * PA / 4; p < (i + 1) * PA / 4; ++p) store_pass<BM, THREADS>(nA, tid, ra[p], p);
 #pragma unroll
-                for (int p = i * PB / 4; p < (i + 1) * PB / 4; ++p) store_pass<BN, THREADS>(nB, tid, rb[p], p);
+                for (int p = i * PB / 4; p < (i + 1) * PB / 4; ++p) store_b(nB, p);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -508,6 +553,11 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (BM >= 128 ? 2 : 1)) vo
     }
     const bool aligned = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
     const bool fast = aligned && (row0 + BM <= g.m) && (col0 + BN <= g.n) && (g.k % BK == 0);
+    if (g.transb) {
+        if (fast) gemm_body<BM, BN, true, true>(g, smem, tile_r, tile_c);
+        else      gemm_body<BM, BN, false, true>(g, smem, tile_r, tile_c);
+        return;
+    }
     if constexpr (BM % 128 == 0) {
         if (fast && !(g.dbg & 16)) { gemm_body_dma<BM, BN>(g, smem, tile_r, tile_c); return; }
     }
@@ -535,11 +585,11 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
     if (bc[0] < 1 || bc[1] < 1 || bc[3] < 1) { set_error("gemm_nt: bad block-cyclic descriptor"); return SGPR_E_ARG; }
     if (m < 0 || n < 0 || k < 0) { set_error("gemm_nt: negative extent"); return SGPR_E_ARG; }
     if (m == 0 || n == 0) return 0;
-    if (lda < (size_t)m || ldb < (size_t)n || ldc < (size_t)m) {
-        set_error("gemm_nt: leading dimension too small");
+    if (lda < (size_t)m || ldb < (size_t)(g_transb_next ? k : n) || ldc < (size_t)m) {
+        set_error("gemm: leading dimension too small");
         return SGPR_E_ARG;
     }
-    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, g_stamps, 0, 0, 0, 0, 0, 0,
+    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, g_transb_next, g_stamps, 0, 0, 0, 0, 0, 0,
                bc[0], bc[1], bc[2], bc[3], bc[4], g_dbg};
     auto set_map = [&](int bm, int bn) {
         g.tiles_m = (m + bm - 1) / bm;
@@ -606,6 +656,16 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
         g_prof.recs.push_back(rec);
     }
     return 0;
+}
+
+// C (m x n) = beta C + alpha A (m x k) B (k x n): the "NN" product (B's k index contiguous)
+int gemm_nn(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
+            double beta, double *C, size_t ldc, hipStream_t st)
+{
+    g_transb_next = 1;
+    const int rc = gemm_nt(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 0, st);
+    g_transb_next = 0;
+    return rc;
 }
 
 void gemm_set_stamps(unsigned long long *dev_buf) { g_stamps = dev_buf; }

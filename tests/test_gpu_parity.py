@@ -570,3 +570,20 @@ def test_fit_matrix_roundtrip(oracle):
             assert np.all(np.triu(Lh, 1) == 0) and np.abs(Lh @ Lh.T - Ko).max() < 1e-12
             X = f.solve_rhs(np.eye(2 * N)[:, :3])
             assert np.abs(Ko @ X - np.eye(2 * N)[:, :3]).max() < 1e-10
+
+
+@pytest.mark.parametrize("n,nrhs", [(40, 8), (129, 17), (1000, 64), (2304, 300)])
+def test_multi_rhs_solve_on_mfma(ops, n, nrhs):
+    """solve_cholesky with many right-hand sides (>= 8) runs as GEMM-shaped panel solves (rows =
+    right-hand sides, 'NT' forward and 'NN' backward products) instead of per-vector TRSVs."""
+    rng = np.random.default_rng(n + nrhs)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T / n + np.eye(n) * 0.5
+    import scipy.linalg
+    Lf = scipy.linalg.cholesky(A, lower=True)
+    B = rng.standard_normal((n, nrhs))
+    X = ops.solve_cholesky(Lf, B)
+    Xr = scipy.linalg.cho_solve((Lf, True), B)
+    assert np.linalg.norm(X - Xr) / np.linalg.norm(Xr) < 1e-12
+    x1 = ops.solve_cholesky(Lf, B[:, 0])
+    assert np.linalg.norm(x1 - Xr[:, 0]) / np.linalg.norm(Xr[:, 0]) < 1e-12
