@@ -77,6 +77,14 @@ int sgpr_build_k_host(int family, int n, int n0, const double *x, const double *
 int sgpr_buildkreg_host(int family, int n, int n0, const double *x, const double *y,
                         const double *x0, const double *y0, const double *hyp, int nhyp,
                         double *K, size_t ldk);
+/* d canonical pairs per point (BASELINE configs d = 2, 3; SURVEY.md 8 preamble): X (n x 2d), X0
+ * (n0 x 2d) column-major, one column per coordinate (q_1..q_d, P_1..P_d), hyp = (lq_1..lq_d,
+ * lP_1..lP_d, sig).  K is (2 d n x 2 d n0): block (a, b) = sig d^2 k / dx_a dx'_b at rows a n,
+ * columns b n0, for the product kernel of family A (periodic q's) or C (all SE).  d = 1 is
+ * sgpr_build_k_host entry for entry; d > 1 has no counterpart in the reference. */
+int sgpr_build_k_nd_host(int family, int d, int n, int n0, const double *X, size_t ldx,
+                         const double *X0, size_t ldx0, const double *hyp, int nhyp, double *K,
+                         size_t ldk);
 /* kernels.<name>_num, batched: out[i] = f(xa[i], ya[i], xb[i], yb[i], l...).  `l` holds
  * (lx, ly) or (lx, ly, p).  replaces the f2py `kernels` module (kernels.f90:1-94) */
 int sgpr_kernel_eval_host(int family, int which, int m, const double *xa, const double *ya,
@@ -105,6 +113,10 @@ typedef struct sgpr_fit *sgpr_fit_t;
 int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, const double *z,
                     const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
                     sgpr_fit_t *out);
+/* the same fit for d canonical pairs per point: X (n_pts x 2d), z (2 d n_pts), order n = 2 d n_pts */
+int sgpr_fit_create_nd(int family, int d, int n_pts, const double *X, size_t ldx, const double *z,
+                       const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
+                       sgpr_fit_t *out);
 /* new hyper-parameters / targets for the next run (the optimiser loop of the drivers,
  * 01_pendulum/implicit/main.py:146-151, calls the path ~100x with fixed x) */
 int sgpr_fit_set_hyp(sgpr_fit_t f, const double *hyp, int nhyp, double sig2n);
@@ -134,6 +146,8 @@ int sgpr_fit_inverse(sgpr_fit_t f, double *Kyinv, size_t ld);
 /* gradient of the nll with respect to (lx, ly) on a solved fit: what nll_grad / nll_grad_reg
  * return as nlp_grad (functions/func.py:132-162) */
 int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2);
+/* K* . alpha for m test points with d pairs each: Xt (m x 2d), out (m x 2d), both column-major */
+int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, double *out);
 /* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
 int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms);
 /* device pointers of the fit (for callers that own a torch / HIP context): K/L, alpha */

@@ -54,6 +54,8 @@ class Oracle:
         for f in (L.orc_build_dk, L.orc_build_dkreg):
             f.restype = C.c_int
             f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t]
+        L.orc_build_k_nd.restype = C.c_int
+        L.orc_build_k_nd.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_size_t]
         L.orc_cholesky_lower.restype = C.c_int
         L.orc_cholesky_lower.argtypes = [C.c_int, _dp, C.c_size_t]
         L.orc_solve_cholesky.restype = None
@@ -85,6 +87,26 @@ class Oracle:
         self.lib.orc_buildkreg(FAMILIES[fam], n, n0, _p(x), _p(y), _p(x0), _p(y0), _p(hyp), _p(K),
                                max(n, 1), threads)
         return K
+
+    def build_K_nd(self, fam, X, X0, hyp):
+        """d canonical pairs: X (n x 2d), X0 (n0 x 2d), hyp = (lq.., lP.., sig) -> K (2dn x 2dn0)."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        X0 = np.asfortranarray(X0, dtype=np.float64)
+        hyp = _f64(hyp)
+        n, D = X.shape
+        n0 = X0.shape[0]
+        K = np.empty((D * n, D * n0), order="F")
+        rc = self.lib.orc_build_k_nd(FAMILIES[fam], D // 2, n, n0, _p(X), _p(X0), _p(hyp), _p(K), max(D * n, 1))
+        if rc:
+            raise ValueError("family not available for d > 1")
+        return K
+
+    def fit_nd(self, fam, X, z, hyp, sig2n):
+        K = self.build_K_nd(fam, X, X, hyp)
+        n = K.shape[0]
+        Lf = self.cholesky(K + abs(sig2n) * np.eye(n))
+        alpha = self.solve_cholesky(Lf, z)
+        return alpha, self.nll(Lf, z, alpha), Lf
 
     def scalar_dl(self, fam, which, xa, ya, xb, yb, lx, ly):
         return self.lib.orc_scalar_dl(FAMILIES[fam], which, xa, ya, xb, yb, lx, ly)

@@ -366,3 +366,48 @@ void orc_predict_reg(int fam, int m, const double *q, const double *P, int n0,
         out[k] = r;
     }
 }
+
+
+/* ---- d canonical pairs (SURVEY.md 8 preamble, 8(f) rank 4) ---------------------------------------
+ * The reference implements one pair only (kernels.f90 takes scalar (x, y)); BASELINE's d = 2, 3
+ * configs generalise it as SURVEY.md recommends: inputs x = (q_1..q_d, P_1..P_d), product kernel
+ *     k(x, x') = prod_m f_m(x_m - x'_m),   f_m periodic (family A) or SE (family C) for the q's,
+ *                                          SE for the P's,
+ * covariance of the gradient observations K_ab = d^2 k / dx_a dx'_b, a, b = 1..2d, i.e.
+ *     K_ab = sig k (a == b ? -f_a''/f_a : -(f_a'/f_a)(f_b'/f_b)).
+ * d = 1 is exactly build_K (sympgpr.f90:12-38): -f''/f are d2kdxdx0 / d2kdydy0 over k and the
+ * cross term is d2kdxdy0 (kernels.f90:58-94).  PARITY UNPINNED BY THE REFERENCE for d > 1: pinned by
+ * the d = 1 reduction and by a sympy differentiation of the product kernel in tests/test_oracle.py
+ * (the technique of the reference's own init_func.py:24-52).
+ * X is (n x 2d) column-major (one column per coordinate); hyp = (lq_1..lq_d, lP_1..lP_d, sig);
+ * K is (2 d n x 2 d n0), block (a, b) at rows a n, columns b n0. */
+int orc_build_k_nd(int fam, int d, int n, int n0, const double *X, const double *X0, const double *hyp,
+                   double *K, size_t ldk)
+{
+    const int D = 2 * d;
+    const double sig = hyp[D];
+    if (fam != FAM_A && fam != FAM_C) return -1;
+    for (int j = 0; j < n0; ++j)
+        for (int i = 0; i < n; ++i) {
+            double g[16], nh[16], arg = 0.0;
+            for (int m = 0; m < D; ++m) {
+                const double l = hyp[m], l2 = l * l;
+                const double dx = X0[j + (size_t)m * n0] - X[i + (size_t)m * n];   /* a = column point */
+                if (m < d && fam == FAM_A) {
+                    const double s = sin(0.5 * dx), c = cos(0.5 * dx);
+                    arg += -0.5 * s * s / l2;
+                    g[m] = -0.5 * s * c / l2;
+                    nh[m] = 0.25 * (l2 * cos(dx) - s * s * c * c) / (l2 * l2);
+                } else {
+                    arg += -0.5 * dx * dx / l2;
+                    g[m] = -dx / l2;
+                    nh[m] = (l2 - dx * dx) / (l2 * l2);
+                }
+            }
+            const double E = sig * exp(arg);
+            for (int a = 0; a < D; ++a)
+                for (int b = 0; b < D; ++b)
+                    K[(size_t)a * n + i + ((size_t)b * n0 + j) * ldk] = E * (a == b ? nh[a] : -g[a] * g[b]);
+        }
+    return 0;
+}

@@ -38,11 +38,15 @@ SIGNATURES = {
                                      C.c_size_t]),
     "sgpr_build_dkreg_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp,
                                         C.c_size_t]),
+    "sgpr_build_k_nd_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_size_t, _dp, C.c_size_t, _dp,
+                                       C.c_int, _dp, C.c_size_t]),
     "sgpr_kernel_eval_host": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "sgpr_potrf_host": (C.c_int, [C.c_int, _dp, C.c_size_t]),
     "sgpr_potrs_host": (C.c_int, [C.c_int, _dp, C.c_size_t, _dp, C.c_size_t, C.c_int]),
     "sgpr_fit_create": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_uint, _vp,
                                   C.POINTER(_vp)]),
+    "sgpr_fit_create_nd": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, C.c_size_t, _dp, _dp, C.c_int, C.c_double,
+                                     C.c_uint, _vp, C.POINTER(_vp)]),
     "sgpr_fit_set_hyp": (C.c_int, [_vp, _dp, C.c_int, C.c_double]),
     "sgpr_fit_set_targets": (C.c_int, [_vp, _dp]),
     "sgpr_fit_build": (C.c_int, [_vp]),
@@ -57,6 +61,7 @@ SIGNATURES = {
     "sgpr_fit_predict_rows": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "sgpr_fit_nll_grad": (C.c_int, [_vp, _dp]),
     "sgpr_fit_inverse": (C.c_int, [_vp, _dp, C.c_size_t]),
+    "sgpr_fit_predict_nd": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t, _dp]),
     "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
     "sgpr_fit_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
     "sgpr_fit_destroy": (C.c_int, [_vp]),

@@ -50,6 +50,9 @@ using namespace sgpr;
 
 struct sgpr_fit {
     int family = 0, npts = 0, n = 0;
+    int d = 1;                 // canonical pairs per point (1 = the reference's layout)
+    double hyp_nd[8] = {};     // (lq.., lP.., sig) for d > 1
+    double *dX = nullptr;      // all coordinates, (npts x 2d) column-major; dx = dX, dy = dX + npts
     unsigned flags = 0;
     hipStream_t st = nullptr;
     KConst kc{};
@@ -190,6 +193,38 @@ int sgpr_build_dkreg_host(int family, int which, int n, int n0, const double *x,
     return 0;
 }
 
+/* d canonical pairs: X (n x 2d), X0 (n0 x 2d) column-major, hyp = (lq_1..lq_d, lP_1..lP_d, sig);
+ * K (2 d n x 2 d n0), block (a, b) at rows a n, columns b n0.  d = 1 == sgpr_build_k_host. */
+int sgpr_build_k_nd_host(int family, int d, int n, int n0, const double *X, size_t ldx, const double *X0,
+                         size_t ldx0, const double *hyp, int nhyp, double *K, size_t ldk)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (d < 1 || d > 3 || n < 0 || n0 < 0 || ldk < (size_t)(2 * d * n) || ldx < (size_t)n || ldx0 < (size_t)n0) {
+        set_error("build_k_nd: bad shape");
+        return SGPR_E_ARG;
+    }
+    if (n == 0 || n0 == 0) return 0;
+    const int D = 2 * d;
+    DevBuf dX, dX0, dK;
+    hipStream_t st = nullptr;
+    if ((rc = dX.alloc((size_t)n * D * sizeof(double))) || (rc = dX0.alloc((size_t)n0 * D * sizeof(double))) ||
+        (rc = dK.alloc((size_t)D * n * D * n0 * sizeof(double))))
+        return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dX.p, (size_t)n * sizeof(double), X, ldx * sizeof(double), (size_t)n * sizeof(double), D,
+                              hipMemcpyHostToDevice, st));
+    SGPR_HIP(hipMemcpy2DAsync(dX0.p, (size_t)n0 * sizeof(double), X0, ldx0 * sizeof(double), (size_t)n0 * sizeof(double), D,
+                              hipMemcpyHostToDevice, st));
+    const size_t ld = (size_t)D * n;
+    if ((rc = gram_nd(family, d, n, n0, dX.as<double>(), (size_t)n, dX0.as<double>(), (size_t)n0, hyp, nhyp,
+                      dK.as<double>(), ld, (size_t)n, (size_t)n0, 0, 0.0, st)))
+        return rc;
+    SGPR_HIP(hipMemcpy2DAsync(K, ldk * sizeof(double), dK.p, ld * sizeof(double), ld * sizeof(double), (size_t)D * n0,
+                              hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 int sgpr_kernel_eval_host(int family, int which, int m, const double *xa, const double *ya,
                           const double *xb, const double *yb, const double *l, int nl, double *out)
 {
@@ -275,7 +310,7 @@ int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, i
 int sgpr_fit_destroy(sgpr_fit_t f)
 {
     if (!f) return 0;
-    for (void *p : {(void *)f->dx, (void *)f->dy, (void *)f->dz, (void *)f->dA, (void *)f->dalpha,
+    for (void *p : {(void *)f->dX, (void *)f->dz, (void *)f->dA, (void *)f->dalpha,
                     (void *)f->dscal, (void *)f->dinfo, f->work})
         if (p) (void)hipFree(p);
     for (auto &e : f->ev)
@@ -284,26 +319,38 @@ int sgpr_fit_destroy(sgpr_fit_t f)
     return 0;
 }
 
-int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, const double *z,
-                    const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
-                    sgpr_fit_t *out)
+static int fit_create_common(int family, int d, int n_pts, const double *X, size_t ldx, const double *x,
+                             const double *y, const double *z, const double *hyp, int nhyp, double sig2n,
+                             unsigned flags, void *stream, sgpr_fit_t *out)
 {
     int rc = need_device();
     if (rc) return rc;
-    if (!out || n_pts <= 0 || !x || !y) { set_error("fit_create: bad arguments"); return SGPR_E_ARG; }
+    if (!out || n_pts <= 0 || (d == 1 ? (!x || !y) : !X)) { set_error("fit_create: bad arguments"); return SGPR_E_ARG; }
     if (flags & SGPR_FIT_KEEP_K) { set_error("fit_create: SGPR_FIT_KEEP_K not implemented"); return SGPR_E_ARG; }
+    if (d != 1 && (flags & SGPR_FIT_REG)) { set_error("fit_create: the scalar-kernel GP exists for d = 1 only"); return SGPR_E_ARG; }
     sgpr_fit *f = new (std::nothrow) sgpr_fit;
     if (!f) return SGPR_E_NOMEM;
-    f->family = family; f->npts = n_pts; f->n = (flags & SGPR_FIT_REG) ? n_pts : 2 * n_pts; f->flags = flags;
+    f->family = family; f->npts = n_pts; f->d = d; f->flags = flags;
+    f->n = (flags & SGPR_FIT_REG) ? n_pts : 2 * d * n_pts;
     f->st = static_cast<hipStream_t>(stream);
-    if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
+    if (d == 1) {
+        if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
+    } else {
+        if (d < 1 || d > 3 || nhyp != 2 * d + 1 || !hyp || (family != SGPR_FAM_A && family != SGPR_FAM_C)) {
+            delete f;
+            set_error("fit_create_nd: d in 1..3, family A or C, hyp = (lq_1..lq_d, lP_1..lP_d, sig)");
+            return SGPR_E_ARG;
+        }
+        for (int i = 0; i < nhyp; ++i) f->hyp_nd[i] = hyp[i];
+    }
     f->sig2n = sig2n;
     const size_t n = (size_t)f->n;
     f->lwork = potrf_workspace(f->n);
     auto fail = [&](int code) { sgpr_fit_destroy(f); return code; };
 #define FIT_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(hip_fail(e__, #call, __FILE__, __LINE__)); } while (0)
-    FIT_HIP(hipMalloc((void **)&f->dx, n_pts * sizeof(double)));
-    FIT_HIP(hipMalloc((void **)&f->dy, n_pts * sizeof(double)));
+    FIT_HIP(hipMalloc((void **)&f->dX, (size_t)2 * d * n_pts * sizeof(double)));
+    f->dx = f->dX;
+    f->dy = f->dX + n_pts;
     FIT_HIP(hipMalloc((void **)&f->dz, n * sizeof(double)));
     FIT_HIP(hipMalloc((void **)&f->dalpha, n * sizeof(double)));
     FIT_HIP(hipMalloc((void **)&f->dscal, 4 * sizeof(double)));
@@ -311,8 +358,13 @@ int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, con
     FIT_HIP(hipMalloc(&f->work, f->lwork));
     FIT_HIP(hipMalloc((void **)&f->dA, n * n * sizeof(double)));
     for (auto &e : f->ev) FIT_HIP(hipEventCreate(&e));
-    FIT_HIP(hipMemcpyAsync(f->dx, x, n_pts * sizeof(double), hipMemcpyHostToDevice, f->st));
-    FIT_HIP(hipMemcpyAsync(f->dy, y, n_pts * sizeof(double), hipMemcpyHostToDevice, f->st));
+    if (d == 1) {
+        FIT_HIP(hipMemcpyAsync(f->dx, x, n_pts * sizeof(double), hipMemcpyHostToDevice, f->st));
+        FIT_HIP(hipMemcpyAsync(f->dy, y, n_pts * sizeof(double), hipMemcpyHostToDevice, f->st));
+    } else {
+        FIT_HIP(hipMemcpy2DAsync(f->dX, n_pts * sizeof(double), X, ldx * sizeof(double), n_pts * sizeof(double),
+                                 (size_t)2 * d, hipMemcpyHostToDevice, f->st));
+    }
     if (z) FIT_HIP(hipMemcpyAsync(f->dz, z, n * sizeof(double), hipMemcpyHostToDevice, f->st));
     else FIT_HIP(hipMemsetAsync(f->dz, 0, n * sizeof(double), f->st));
     FIT_HIP(hipStreamSynchronize(f->st));
@@ -321,11 +373,35 @@ int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, con
     return 0;
 }
 
+int sgpr_fit_create(int family, int n_pts, const double *x, const double *y, const double *z,
+                    const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
+                    sgpr_fit_t *out)
+{
+    return fit_create_common(family, 1, n_pts, nullptr, 0, x, y, z, hyp, nhyp, sig2n, flags, stream, out);
+}
+
+int sgpr_fit_create_nd(int family, int d, int n_pts, const double *X, size_t ldx, const double *z,
+                       const double *hyp, int nhyp, double sig2n, unsigned flags, void *stream,
+                       sgpr_fit_t *out)
+{
+    if (d == 1) {
+        if (!X || ldx < (size_t)n_pts) { set_error("fit_create_nd: bad X"); return SGPR_E_ARG; }
+        return fit_create_common(family, 1, n_pts, nullptr, 0, X, X + ldx, z, hyp, nhyp, sig2n, flags, stream, out);
+    }
+    if (!X || ldx < (size_t)(n_pts > 0 ? n_pts : 1)) { set_error("fit_create_nd: bad X"); return SGPR_E_ARG; }
+    return fit_create_common(family, d, n_pts, X, ldx, nullptr, nullptr, z, hyp, nhyp, sig2n, flags, stream, out);
+}
+
 int sgpr_fit_set_hyp(sgpr_fit_t f, const double *hyp, int nhyp, double sig2n)
 {
     if (!f) { set_error("null fit"); return SGPR_E_ARG; }
-    int rc = make_kconst(f->family, hyp, nhyp, &f->kc);
-    if (rc) return rc;
+    if (f->d > 1) {
+        if (!hyp || nhyp != 2 * f->d + 1) { set_error("fit_set_hyp: hyp = (lq.., lP.., sig)"); return SGPR_E_ARG; }
+        for (int i = 0; i < nhyp; ++i) f->hyp_nd[i] = hyp[i];
+    } else {
+        int rc = make_kconst(f->family, hyp, nhyp, &f->kc);
+        if (rc) return rc;
+    }
     f->sig2n = sig2n;
     f->built = f->factored = f->solved = false;
     return 0;
@@ -349,7 +425,11 @@ int sgpr_fit_build(sgpr_fit_t f)
     if (f->flags & SGPR_FIT_LOWER_ONLY) flags |= SGPR_G_LOWER;
     SGPR_HIP(hipEventRecord(f->ev[0], f->st));
     int rc;
-    if (f->flags & SGPR_FIT_REG) {
+    if (f->d > 1) {
+        // d canonical pairs: (2d)^2 blocks of N x N, block (a, b) at rows a N, columns b N
+        rc = gram_nd(f->family, f->d, N, N, f->dX, (size_t)N, f->dX, (size_t)N, f->hyp_nd, 2 * f->d + 1, f->dA, n,
+                     (size_t)N, (size_t)N, 0, std::fabs(f->sig2n), f->st);
+    } else if (f->flags & SGPR_FIT_REG) {
         // Ky = buildKreg(x, x) + |sig2n| I  (func.py:182-183)
         rc = gram_reg(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, n, 0, std::fabs(f->sig2n), f->st);
     } else
@@ -482,6 +562,7 @@ int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P,
 {
     if (!f || m < 0 || !q || !P || !out_p || !out_q) { set_error("fit_predict_rows: bad arguments"); return SGPR_E_ARG; }
     if (!f->solved) { set_error("fit_predict_rows: not solved"); return SGPR_E_STATE; }
+    if (f->d > 1) { set_error("fit_predict_rows: use sgpr_fit_predict_nd for d > 1"); return SGPR_E_STATE; }
     if (m == 0) return 0;
     DevBuf dq, dP, dop, doq;
     int rc;
@@ -536,6 +617,7 @@ int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2)
 {
     if (!f || !grad2) { set_error("null argument"); return SGPR_E_ARG; }
     if (!f->solved) { set_error("fit_nll_grad: run the fit first"); return SGPR_E_STATE; }
+    if (f->d > 1) { set_error("fit_nll_grad: available for d = 1"); return SGPR_E_STATE; }
     const size_t n = (size_t)f->n;
     const int N = f->npts;
     DevBuf W, T, tmp, sc;
@@ -566,6 +648,29 @@ int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2)
     SGPR_HIP(hipMemcpyAsync(h, s, 4 * sizeof(double), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
     for (int which = 0; which < 2; ++which) grad2[which] = -0.5 * (-h[2 * which]) + 0.5 * h[2 * which + 1];
+    return 0;
+}
+
+/* K*(2d x 2d N) . alpha for m test points Xt (m x 2d, column-major, leading dimension ldxt):
+ * out (m x 2d, column-major, ld m): column a = predicted d F / d x_a */
+int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, double *out)
+{
+    if (!f || m < 0 || !Xt || !out || ldxt < (size_t)(m > 0 ? m : 1)) { set_error("fit_predict_nd: bad arguments"); return SGPR_E_ARG; }
+    if (!f->solved) { set_error("fit_predict_nd: not solved"); return SGPR_E_STATE; }
+    if (m == 0) return 0;
+    const int D = 2 * f->d;
+    DevBuf dT, dO;
+    int rc;
+    if ((rc = dT.alloc((size_t)m * D * sizeof(double))) || (rc = dO.alloc((size_t)m * D * sizeof(double)))) return rc;
+    SGPR_HIP(hipMemcpy2DAsync(dT.p, (size_t)m * sizeof(double), Xt, ldxt * sizeof(double), (size_t)m * sizeof(double), D,
+                              hipMemcpyHostToDevice, f->st));
+    double hyp1[3] = {f->kc.lx, f->kc.ly, f->kc.sig};
+    const double *hyp = f->d > 1 ? f->hyp_nd : hyp1;
+    if ((rc = predict_nd(f->family, f->d, m, dT.as<double>(), (size_t)m, f->npts, f->dX, (size_t)f->npts, hyp, D + 1,
+                         f->dalpha, dO.as<double>(), f->st)))
+        return rc;
+    SGPR_HIP(hipMemcpyAsync(out, dO.p, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
     return 0;
 }
 

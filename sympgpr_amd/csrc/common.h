@@ -57,6 +57,13 @@ int applymap(int family, int wrap, int nm, int ntest, int n0, const double *xtr,
              const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
              double *pmap, hipStream_t st);
 
+// ---- gram_nd.hip : d canonical pairs per point (X: points x 2d, column-major)
+int gram_nd(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa, size_t ldxa,
+            const double *hyp, int nhyp, double *K, size_t ld, size_t rstride, size_t cstride, long diag_off,
+            double noise, hipStream_t st);
+int predict_nd(int family, int d, int m, const double *Xt, size_t ldxt, int n0, const double *Xtr, size_t ldxtr,
+               const double *hyp, int nhyp, const double *alpha, double *out, hipStream_t st);
+
 // ---- gemm_f64.hip : C = beta C + alpha A B^T on fp64 MFMA tiles
 int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
             size_t ldb, double beta, double *C, size_t ldc, int lower, long diag_off,

@@ -28,6 +28,37 @@ class SympFit:
                                           L.dptr(hyp), len(hyp), float(sig2n), flags,
                                           C.c_void_p(stream or 0), C.byref(self._h)), "sgpr_fit_create")
 
+    @classmethod
+    def pairs(cls, family, X, z, hyp, sig2n, stream=None):
+        """d canonical pairs per point (BASELINE configs d = 2, 3): X is (n_pts, 2d) with columns
+        (q_1..q_d, P_1..P_d), hyp = (lq_1..lq_d, lP_1..lP_d, sig), z has 2*d*n_pts entries ordered
+        block by block like the rows of K.  d = 1 is the reference's layout."""
+        self = cls.__new__(cls)
+        self._lib = L.load_library()
+        self._h = C.c_void_p()
+        X = np.asfortranarray(X, dtype=np.float64)
+        if X.ndim != 2 or X.shape[1] % 2:
+            raise ValueError("X must be (n_pts, 2d)")
+        self.n_pts, D = X.shape
+        self.d = D // 2
+        self.n = D * self.n_pts
+        hyp = L.f64(hyp)
+        z = L.f64(z) if z is not None else np.zeros(self.n)
+        if z.shape != (self.n,):
+            raise ValueError("z must have length %d" % self.n)
+        L.check(self._lib.sgpr_fit_create_nd(L.family_id(family), self.d, self.n_pts, L.dptr(X), max(self.n_pts, 1),
+                                             L.dptr(z), L.dptr(hyp), len(hyp), float(sig2n), 0,
+                                             C.c_void_p(stream or 0), C.byref(self._h)), "sgpr_fit_create_nd")
+        return self
+
+    def predict_pairs(self, Xt):
+        """K* . alpha for test points Xt (m, 2d) -> (m, 2d): column a = predicted dF/dx_a."""
+        Xt = np.asfortranarray(np.atleast_2d(Xt), dtype=np.float64)
+        m = Xt.shape[0]
+        out = np.empty((m, Xt.shape[1]), order="F")
+        L.check(self._lib.sgpr_fit_predict_nd(self._h, m, L.dptr(Xt), max(m, 1), L.dptr(out)), "sgpr_fit_predict_nd")
+        return out
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.sgpr_fit_destroy(self._h)

@@ -128,3 +128,21 @@ def build_dkreg(x, y, x0, y0, hyp, family=None):
                 "sgpr_build_dkreg_host")
         out.append(D)
     return out
+
+
+def build_k_nd(X, X0, hyp, family=None):
+    """d canonical pairs per point: X (n, 2d), X0 (n0, 2d), hyp = (lq.., lP.., sig) -> K (2dn, 2dn0),
+    block (a, b) = sig d^2k/dx_a dx'_b.  d = 1 equals build_k."""
+    lib = L.load_library()
+    X = np.asfortranarray(X, dtype=np.float64)
+    X0 = np.asfortranarray(X0, dtype=np.float64)
+    hyp = L.f64(hyp)
+    n, D = X.shape
+    n0 = X0.shape[0]
+    if X0.shape[1] != D or D % 2:
+        raise ValueError("X and X0 must be (n, 2d) and (n0, 2d)")
+    K = np.empty((D * n, D * n0), order="F")
+    L.check(lib.sgpr_build_k_nd_host(L.family_id(family or _FAMILY), D // 2, n, n0, L.dptr(X), max(n, 1), L.dptr(X0),
+                                     max(n0, 1), L.dptr(hyp), len(hyp), L.dptr(K), max(D * n, 1)),
+            "sgpr_build_k_nd_host")
+    return K

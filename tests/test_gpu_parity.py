@@ -587,3 +587,41 @@ def test_multi_rhs_solve_on_mfma(ops, n, nrhs):
     assert np.linalg.norm(X - Xr) / np.linalg.norm(Xr) < 1e-12
     x1 = ops.solve_cholesky(Lf, B[:, 0])
     assert np.linalg.norm(x1 - Xr[:, 0]) / np.linalg.norm(Xr[:, 0]) < 1e-12
+
+
+# ---------------------------------------------------------------- d canonical pairs (BASELINE d = 2, 3)
+@pytest.mark.parametrize("fam,d,n,n0", [("A", 1, 37, 21), ("A", 2, 600, 70), ("C", 2, 33, 1025), ("A", 3, 130, 64),
+                                        ("C", 3, 1, 5)])
+def test_build_k_nd_vs_oracle(ops, oracle, fam, d, n, n0):
+    rng = np.random.default_rng(1000 * d + n)
+    X = np.column_stack([rng.uniform(0, 2 * np.pi, (n, d)), rng.uniform(-3, 3, (n, d))])
+    X0 = np.column_stack([rng.uniform(0, 2 * np.pi, (n0, d)), rng.uniform(-3, 3, (n0, d))])
+    hyp = np.append(rng.uniform(0.5, 1.5, 2 * d), 0.8)
+    K = ops.build_k_nd(X, X0, hyp, family=fam)
+    Ko = oracle.build_K_nd(fam, X, X0, hyp)
+    assert gram_close(K, Ko)
+    if d == 1:   # one pair: exactly the reference's build_K
+        K1 = np.empty((2 * n, 2 * n0), order="F")
+        ops.build_k(X[:, 0], X[:, 1], X0[:, 0], X0[:, 1], hyp, K1, family=fam)
+        assert gram_close(K, K1)
+
+
+@pytest.mark.parametrize("fam,d,N", [("A", 2, 300), ("C", 3, 200), ("A", 1, 150)])
+def test_fit_pairs_vs_oracle(oracle, fam, d, N):
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(7 * d + N)
+    X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
+    z = rng.standard_normal(2 * d * N)
+    l = 1.2 * (12 * np.pi / N) ** (1.0 / (2 * d))
+    hyp = np.append(np.full(2 * d, l), 1.0)
+    s2 = 1e-2 / l**2
+    a_o, nll_o, _ = oracle.fit_nd(fam, X, z, hyp, s2)
+    with SympFit.pairs(fam, X, z, hyp, s2) as f:
+        f.run()
+        a, nll = f.alpha(), f.nll()
+        pred = f.predict_pairs(X[:17])
+    assert np.linalg.norm(a - a_o) / np.linalg.norm(a_o) < 1e-10
+    assert nll == pytest.approx(nll_o, rel=1e-11)
+    # K alpha at training points = z - sig2n alpha
+    Kalpha = (z - s2 * a).reshape(2 * d, N).T[:17]
+    np.testing.assert_allclose(pred, Kalpha, atol=1e-9)

@@ -156,3 +156,42 @@ def test_nll_grad_is_the_gradient(oracle):
             assert g[i] == pytest.approx(fd, rel=1e-6, abs=1e-7)
         alpha, nll, _ = oracle.fit(fam, x[:Np], x[Np:], y, hyp[:3], hyp[3])
         assert val == pytest.approx(nll, rel=1e-12)
+
+
+def test_build_K_nd_reduces_to_build_K_for_one_pair(oracle, gram):
+    for fam in "AC":
+        g = lambda k: gram[f"{fam}_rect5x7_{k}"]
+        X = np.column_stack((g("x"), g("y")))
+        X0 = np.column_stack((g("x0"), g("y0")))
+        K = oracle.build_K_nd(fam, X, X0, g("hyp"))
+        assert np.abs(K - g("K")).max() <= 4e-16 * np.abs(g("K")).max()
+
+
+@pytest.mark.parametrize("fam,d", [("A", 2), ("C", 2), ("A", 3)])
+def test_build_K_nd_against_sympy(oracle, fam, d):
+    """d > 1 is not in the reference: the oracle is pinned on a symbolic differentiation of the
+    product kernel, the technique of the reference's own generator (01_pendulum/implicit/
+    init_func.py:24-52: define k, differentiate, evaluate)."""
+    import sympy as sp
+    D = 2 * d
+    xa = sp.symbols("xa0:%d" % D)
+    xb = sp.symbols("xb0:%d" % D)
+    ls = sp.symbols("l0:%d" % D, positive=True)
+    k = 1
+    for m in range(D):
+        if m < d and fam == "A":
+            k *= sp.exp(-sp.sin((xa[m] - xb[m]) / 2) ** 2 / (2 * ls[m] ** 2))
+        else:
+            k *= sp.exp(-(xa[m] - xb[m]) ** 2 / (2 * ls[m] ** 2))
+    H = [[sp.lambdify(xa + xb + ls, sp.diff(k, xa[a], xb[b]), "mpmath") for b in range(D)] for a in range(D)]
+    rng = np.random.default_rng(100 * d + ord(fam))
+    n, n0 = 3, 2
+    X = rng.uniform(-1.5, 1.5, (n, D)); X0 = rng.uniform(-1.5, 1.5, (n0, D))
+    l = rng.uniform(0.6, 1.4, D); sig = 0.7
+    K = oracle.build_K_nd(fam, X, X0, np.append(l, sig))
+    for a in range(D):
+        for b in range(D):
+            for i in range(n):
+                for j in range(n0):
+                    ref = sig * float(H[a][b](*X0[j], *X[i], *l))   # a = column ("0") point, as in build_K
+                    assert K[a * n + i, b * n0 + j] == pytest.approx(ref, rel=1e-12, abs=1e-14)
