@@ -31,6 +31,16 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spe
 MFMA_F64_PEAK_TF = 78.6   # MI355X fp64 matrix peak, vendor spec
 
 
+def synth_pairs(n_pts, d, seed=1234):
+    """d canonical pairs per point: q_i ~ U(0, 2pi), P_i ~ U(-3, 3); l = 2 (12 pi)^(1/2) N^(-1/(2d)) keeps
+    about the same number of neighbours within a length scale as the d = 1 setting."""
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([rng.uniform(0, 2 * np.pi, (n_pts, d)), rng.uniform(-3, 3, (n_pts, d))])
+    z = rng.standard_normal(2 * d * n_pts)
+    l = 2.0 * np.sqrt(12 * np.pi) * n_pts ** (-1.0 / (2 * d))
+    return X, z, np.append(np.full(2 * d, l), 1.0), 1e-2 / l**2
+
+
 def synth(n_pts, seed=1234):
     """q ~ U(0, 2pi), P ~ U(-3, 3), z ~ N(0,1); l = 2 sqrt(12 pi / N), sig = 1,
     sig2n = 1e-2 / l^2 (bounded condition number)."""
@@ -90,6 +100,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2N)")
     ap.add_argument("--family", default="A")
+    ap.add_argument("--d", type=int, default=1,
+                    help="canonical pairs per training point (matrix order n = 2*d*N); 1 = the reference's "
+                         "(q, P) layout, 2 / 3 = BASELINE configs 03_henon_heiles / 05_tokamak")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--nb", type=int, default=1024, help="block size of the multi-GPU block-cyclic layout")
     ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
@@ -133,12 +146,17 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         from sympgpr_amd.dist_bench import run_distributed
         return run_distributed(args, rank, local_rank, world, synth, METRIC,
-                               {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS})
+                               {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS}, synth_pairs)
 
     n_pts = args.n_pts
-    n = 2 * n_pts
-    q, P, z, hyp, s2 = synth(n_pts)
-    fit = SympFit(args.family, q, P, z, hyp, s2, lower_only=args.lower_only)
+    d = args.d
+    n = 2 * d * n_pts
+    if d == 1:
+        q, P, z, hyp, s2 = synth(n_pts)
+        fit = SympFit(args.family, q, P, z, hyp, s2, lower_only=args.lower_only)
+    else:
+        X, z, hyp, s2 = synth_pairs(n_pts, d)
+        fit = SympFit.pairs(args.family, X, z, hyp, s2)
 
     for _ in range(args.warmup):
         fit.run()
@@ -161,9 +179,15 @@ def main():
     a = fit.alpha()
     m = min(n_pts, 2048)
     idx = np.random.default_rng(0).choice(n_pts, m, replace=False)
-    op, oq = fit.predict_rows(q[idx], P[idx])
-    r = np.concatenate([op + s2 * a[idx] - z[idx], oq + s2 * a[n_pts + idx] - z[n_pts + idx]])
-    resid = float(np.linalg.norm(r) / np.linalg.norm(np.concatenate([z[idx], z[n_pts + idx]])))
+    if d == 1:
+        op, oq = fit.predict_rows(q[idx], P[idx])
+        r = np.concatenate([op + s2 * a[idx] - z[idx], oq + s2 * a[n_pts + idx] - z[n_pts + idx]])
+        resid = float(np.linalg.norm(r) / np.linalg.norm(np.concatenate([z[idx], z[n_pts + idx]])))
+    else:
+        pred = fit.predict_pairs(X[idx])                       # (m, 2d): K alpha at training points
+        zz = z.reshape(2 * d, n_pts).T[idx]
+        aa = a.reshape(2 * d, n_pts).T[idx]
+        resid = float(np.linalg.norm(pred + s2 * aa - zz) / np.linalg.norm(zz))
     nll = fit.nll()
     fit.close()
 
@@ -176,9 +200,11 @@ def main():
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "synthetic d=2 N=%d: matrix order n=%d (%.1f GB fp64), family %s, "
-                               "l=2*sqrt(12pi/N), sig2n=1e-2/l^2" % (n_pts, n, 8.0 * n * n / 1e9, args.family),
-                   "n_pts": n_pts, "order_n": n, "triangle": "lower" if args.lower_only else "full"},
+        "config": {"workload": "synthetic N=%d points, %s: matrix order n=%d (%.1f GB fp64), family %s, "
+                               "sig2n=1e-2/l^2" % (n_pts, "d=2 input coordinates (q,P), l=2*sqrt(12pi/N)" if d == 1 else
+                                                   "%d canonical pairs per point" % d, n, 8.0 * n * n / 1e9, args.family),
+                   "n_pts": n_pts, "pairs_per_point": d, "order_n": n,
+                   "triangle": "lower" if args.lower_only else "full"},
         "gram_gb_s": gram_bytes / (stage[0] * 1e-3) / 1e9,
         "gram_ms": stage[0],
         "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12,
@@ -193,7 +219,7 @@ def main():
     traffic = {}
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_n131072.json")))
-        if pm["config"]["n_pts"] == n_pts and pm["config"]["family"] == args.family and not args.lower_only:
+        if pm["config"]["n_pts"] == n_pts and pm["config"]["family"] == args.family and not args.lower_only and d == 1:
             traffic = {"gemm": pm["gemm_nt_kernel<256, 128>"]["traffic_bytes_per_launch"],
                        "gram": pm["gram_pairs_kernel"]["traffic_bytes_per_launch"]}
     except Exception:
@@ -207,10 +233,10 @@ def main():
                            "launches": int(big_n), "flop_per_launch": big_flop / big_n,
                            "avg_launch_ms": big_ms / big_n,
                            "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}
-    out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel", "achieved": out["gram_gb_s"],
+    out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel" if d == 1 else "gram_nd_kernel", "achieved": out["gram_gb_s"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["gram_gb_s"] / HBM_PEAK_GBS,
                             "traffic": traffic.get("gram")}
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and d == 1:
         cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family, args.cpu_sample)
         with SympFit(args.family, qs, Ps, zs, hs, s2s) as fs:
             a_gpu = fs.run().alpha()

@@ -170,6 +170,11 @@ int sgpr_gram_reg_dev(int family, int mi, int mj, const double *xb, const double
                       const double *xa, const double *ya, const double *hyp, int nhyp,
                       double *G, size_t ld, long diag_off, double noise, void *stream);
 
+/* Pair-tile Gram build for d canonical pairs per point: Xb (mi x 2d), Xa (mj x 2d) column-major;
+ * block (a, b) of the output at K + a*rstride + b*cstride*ld, each mi x mj. */
+int sgpr_gram_nd_dev(int family, int d, int mi, int mj, const double *Xb, size_t ldxb,
+                     const double *Xa, size_t ldxa, const double *hyp, int nhyp, double *K, size_t ld,
+                     size_t rstride, size_t cstride, long diag_off, double noise, void *stream);
 /* workspace (bytes) sgpr_potrf_dev / sgpr_trsm_rlt_dev need for order n */
 size_t sgpr_potrf_workspace(int n);
 /* lower Cholesky in place; only the lower triangle of A is read or written.
@@ -203,6 +208,11 @@ int sgpr_gemv_sub_dev(int trans, int m, int k, const double *A, size_t lda, cons
 int sgpr_predict_rows_dev(int family, int m, const double *q, const double *P, int n0,
                           const double *xtrain, const double *ytrain, const double *hyp, int nhyp,
                           const double *alpha, double *out_p, double *out_q, void *stream);
+/* the same for d canonical pairs: Xt (m x 2d), Xtrain (n0 x 2d), alpha (2 d n0), out (m x 2d),
+ * all column-major device buffers */
+int sgpr_predict_nd_dev(int family, int d, int m, const double *Xt, size_t ldxt, int n0,
+                        const double *Xtrain, size_t ldxtr, const double *hyp, int nhyp,
+                        const double *alpha, double *out, void *stream);
 /* Kstar(1 x n0) . alpha with the scalar kernel (sympgpr.f90:62-73 guessP) */
 int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, int n0,
                          const double *xtrain, const double *ytrain, const double *hyp, int nhyp,

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sgpr_fit_destroy": (C.c_int, [_vp]),
     "sgpr_gram_pairs_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp,
                                       _vp, C.c_size_t, C.c_long, C.c_double, C.c_uint, _vp]),
+    "sgpr_gram_nd_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _dp, C.c_int,
+                                   _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_long, C.c_double, _vp]),
     "sgpr_gram_reg_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, C.c_int, _vp, C.c_size_t,
                                     C.c_long, C.c_double, _vp]),
     "sgpr_potrf_workspace": (C.c_size_t, [C.c_int]),
@@ -89,6 +91,8 @@ SIGNATURES = {
     "sgpr_gemv_sub_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
     "sgpr_predict_rows_dev": (C.c_int, [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp,
                                         _vp]),
+    "sgpr_predict_nd_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, _dp, C.c_int,
+                                      _vp, _vp, _vp]),
     "sgpr_predict_reg_dev": (C.c_int, [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp]),
     "sgpr_applymap_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
                                      C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -724,6 +724,16 @@ int sgpr_gram_reg_dev(int family, int mi, int mj, const double *xb, const double
                     static_cast<hipStream_t>(stream));
 }
 
+int sgpr_gram_nd_dev(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa,
+                     size_t ldxa, const double *hyp, int nhyp, double *K, size_t ld, size_t rstride,
+                     size_t cstride, long diag_off, double noise, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return gram_nd(family, d, mi, mj, Xb, ldxb, Xa, ldxa, hyp, nhyp, K, ld, rstride, cstride, diag_off,
+                   std::fabs(noise), static_cast<hipStream_t>(stream));
+}
+
 size_t sgpr_potrf_workspace(int n) { return potrf_workspace(n); }
 
 int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, void *stream)
@@ -788,6 +798,14 @@ int sgpr_predict_rows_dev(int family, int m, const double *q, const double *P, i
     if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
     return predict_rows(family, m, q, P, n0, xtrain, ytrain, kc, alpha, out_p, out_q,
                         static_cast<hipStream_t>(stream));
+}
+
+int sgpr_predict_nd_dev(int family, int d, int m, const double *Xt, size_t ldxt, int n0, const double *Xtrain,
+                        size_t ldxtr, const double *hyp, int nhyp, const double *alpha, double *out, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return predict_nd(family, d, m, Xt, ldxt, n0, Xtrain, ldxtr, hyp, nhyp, alpha, out, static_cast<hipStream_t>(stream));
 }
 
 int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, int n0, const double *xtrain,

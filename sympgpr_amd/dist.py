@@ -75,6 +75,12 @@ class HipOps:
     def work_size(self, nb):
         return (self.lib.sgpr_potrf_workspace(nb) + 7) // 8  # in doubles
 
+    def gram_nd(self, fam, d, mi, mj, Xb, Xa, hyp, A, ld):
+        """(2d)^2 blocks of mi x mj for d canonical pairs; Xb (mi x 2d), Xa (mj x 2d) column-major."""
+        hyp = L.f64(hyp)
+        L.check(self.lib.sgpr_gram_nd_dev(L.family_id(fam), d, mi, mj, self._p(Xb), mi, self._p(Xa), mj, L.dptr(hyp),
+                                          len(hyp), self._p(A), ld, mi, mj, 0, 0.0, self.stream()), "sgpr_gram_nd_dev")
+
     def gram_pairs(self, fam, mi, mj, xb, yb, xa, ya, hyp, A, offs, ld, flags):
         """offs: element offsets of the qq / Pq / qP / PP parts inside A (or None)."""
         hyp = L.f64(hyp)
@@ -114,14 +120,21 @@ class DistFit:
 
     _BIG = 1 << 60
 
-    def __init__(self, ops, family, x, y, z, hyp, sig2n, nb=1024, group=None):
+    def __init__(self, ops, family, x, y, z, hyp, sig2n, nb=1024, group=None, X=None):
+        """x, y: the (q, P) coordinates of the reference's one-pair layout; or X (N x 2d) for d
+        canonical pairs per point (then x, y are ignored and hyp = (lq.., lP.., sig))."""
         self.ops, self.family = ops, family
+        self.X = None if X is None else np.asfortranarray(X, dtype=np.float64)
+        self.d = 1 if X is None else self.X.shape[1] // 2
+        if X is not None:
+            x = self.X[:, 0]
+            y = self.X[:, self.d]
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.group = group
         self.pr, self.pc = grid_shape(self.world)
         self.pi, self.pj = self.rank % self.pr, self.rank // self.pr
         self.N = len(x)
-        self.n = 2 * self.N
+        self.n = 2 * self.d * self.N
         self.nb = nb
         if self.N % nb:
             raise ValueError("the number of training points must be a multiple of the block size nb")
@@ -164,11 +177,17 @@ class DistFit:
         rsel = np.concatenate([np.arange(I * nb, (I + 1) * nb) for I in self.rows if I < nbN])
         csel = np.concatenate([np.arange(J * nb, (J + 1) * nb) for J in self.cols if J < nbN])
         dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ops.device)
-        xb, yb, xa, ya = dev(self.x[rsel]), dev(self.y[rsel]), dev(self.x[csel]), dev(self.y[csel])
         mi, mj = len(rsel), len(csel)
         ld = self.mloc
-        offs = [0, mi, mj * ld, mi + mj * ld]   # qq, Pq, qP, PP
-        ops.gram_pairs(self.family, mi, mj, xb, yb, xa, ya, self.hyp, self.A, offs, ld, L.G_ALL)
+        if self.X is None:
+            xb, yb, xa, ya = dev(self.x[rsel]), dev(self.y[rsel]), dev(self.x[csel]), dev(self.y[csel])
+            offs = [0, mi, mj * ld, mi + mj * ld]   # qq, Pq, qP, PP
+            ops.gram_pairs(self.family, mi, mj, xb, yb, xa, ya, self.hyp, self.A, offs, ld, L.G_ALL)
+        else:
+            # d pairs: the same row / column selection in each of the 2d coordinate blocks
+            Xb = dev(np.asfortranarray(self.X[rsel]).T.copy()).reshape(-1)   # (mi x 2d) column-major, flat
+            Xa = dev(np.asfortranarray(self.X[csel]).T.copy()).reshape(-1)
+            ops.gram_nd(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld)
         # |sig2n| on the global diagonal: the diagonal blocks this rank owns
         for li, I in enumerate(self.rows):
             if I % self.pc == self.pj:

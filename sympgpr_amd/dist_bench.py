@@ -9,16 +9,22 @@ import torch
 import torch.distributed as dist
 
 
-def run_distributed(args, rank, local_rank, world, synth, metric, peaks):
+def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_pairs=None):
     from .dist import DistFit, HipOps, grid_shape
     dev = torch.device("cuda", local_rank)
     ops = HipOps(dev)
     n_pts = args.n_pts
-    n = 2 * n_pts
-    q, P, z, hyp, s2 = synth(n_pts)
+    d = getattr(args, "d", 1)
+    n = 2 * d * n_pts
     pr, pc = grid_shape(world)
     nb = args.nb
-    fit = DistFit(ops, args.family, q, P, z, hyp, s2, nb=nb)
+    if d == 1:
+        q, P, z, hyp, s2 = synth(n_pts)
+        fit = DistFit(ops, args.family, q, P, z, hyp, s2, nb=nb)
+        X = np.column_stack((q, P))
+    else:
+        X, z, hyp, s2 = synth_pairs(n_pts, d)
+        fit = DistFit(ops, args.family, None, None, z, hyp, s2, nb=nb, X=X)
 
     def barrier():
         dist.barrier()
@@ -62,25 +68,26 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks):
     a = fit.alpha.cpu().numpy()
     resid = None
     if rank == 0:
-        from .fit import SympFit  # only its K*-row kernel is used (no factorisation)
         m = min(n_pts, 512)
         idx = np.random.default_rng(0).choice(n_pts, m, replace=False)
         lib = ops.lib
         from . import _lib as L
         import ctypes as C
-        d = lambda v: torch.as_tensor(np.ascontiguousarray(v)).to(dev)
-        dq, dP, dx, dy, da = d(q[idx]), d(P[idx]), d(q), d(P), d(a)
-        op_, oq_ = torch.empty(m, dtype=torch.float64, device=dev), torch.empty(m, dtype=torch.float64, device=dev)
-        hyp64 = L.f64(hyp)
-        L.check(lib.sgpr_predict_rows_dev(L.family_id(args.family), m, C.c_void_p(dq.data_ptr()),
-                                          C.c_void_p(dP.data_ptr()), n_pts, C.c_void_p(dx.data_ptr()),
-                                          C.c_void_p(dy.data_ptr()), L.dptr(hyp64), len(hyp64),
-                                          C.c_void_p(da.data_ptr()), C.c_void_p(op_.data_ptr()),
-                                          C.c_void_p(oq_.data_ptr()), None))
+        dv = lambda v: torch.as_tensor(np.ascontiguousarray(v)).to(dev)
+        D = 2 * d
+        dXt = dv(np.asfortranarray(X[idx]).T.copy()).reshape(-1)     # (m x 2d) column-major, flat
+        dXtr = dv(np.asfortranarray(X).T.copy()).reshape(-1)
+        da = dv(a)
+        out_t = torch.empty(m * D, dtype=torch.float64, device=dev)
+        hyp_nd = L.f64(hyp)                                          # (lq.., lP.., sig): d = 1 is (lx, ly, sig)
+        L.check(lib.sgpr_predict_nd_dev(L.family_id(args.family), d, m, C.c_void_p(dXt.data_ptr()), m, n_pts,
+                                        C.c_void_p(dXtr.data_ptr()), n_pts, L.dptr(hyp_nd), len(hyp_nd),
+                                        C.c_void_p(da.data_ptr()), C.c_void_p(out_t.data_ptr()), None))
         torch.cuda.synchronize()
-        op_, oq_ = op_.cpu().numpy(), oq_.cpu().numpy()
-        r = np.concatenate([op_ + s2 * a[idx] - z[idx], oq_ + s2 * a[n_pts + idx] - z[n_pts + idx]])
-        resid = float(np.linalg.norm(r) / np.linalg.norm(np.concatenate([z[idx], z[n_pts + idx]])))
+        pred = out_t.cpu().numpy().reshape(D, m).T
+        zz = z.reshape(D, n_pts).T[idx]
+        aa = a.reshape(D, n_pts).T[idx]
+        resid = float(np.linalg.norm(pred + s2 * aa - zz) / np.linalg.norm(zz))
 
     if rank == 0:
         chol_flop = n**3 / 3.0
@@ -91,9 +98,11 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "synthetic d=2 N=%d: matrix order n=%d (%.1f GB fp64) 2-D block-cyclic %dx%d, "
-                                   "nb=%d, family %s" % (n_pts, n, 8.0 * n * n / 1e9, pr, pc, nb, args.family),
-                       "n_pts": n_pts, "order_n": n, "grid": [pr, pc], "nb": nb},
+            "config": {"workload": "synthetic N=%d points, %s: matrix order n=%d (%.1f GB fp64) 2-D block-cyclic %dx%d, "
+                                   "nb=%d, family %s" % (n_pts, "d=2 input coordinates (q,P)" if d == 1 else
+                                                         "%d canonical pairs per point" % d, n, 8.0 * n * n / 1e9, pr,
+                                                         pc, nb, args.family),
+                       "n_pts": n_pts, "pairs_per_point": d, "order_n": n, "grid": [pr, pc], "nb": nb},
             "gram_gb_s": 8.0 * n * n / (stage[0] * 1e-3) / 1e9, "gram_ms": stage[0],
             "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12, "chol_ms": stage[1],
             "solve_ms": stage[2], "residual_Ky_alpha_minus_z": resid, "nll": fit.nll,

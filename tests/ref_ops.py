@@ -37,6 +37,11 @@ class RefOps:
             if off is not None:
                 _mat(A, off, mi, mj, ld)[:, :] = K[r0:r0 + mi, c0:c0 + mj]
 
+    def gram_nd(self, fam, d, mi, mj, Xb, Xa, hyp, A, ld):
+        D = 2 * d
+        K = self.oracle.build_K_nd(fam, Xb.numpy().reshape(D, mi).T, Xa.numpy().reshape(D, mj).T, hyp)
+        _mat(A, 0, D * mi, D * mj, ld)[:, :] = K
+
     def potrf(self, nb, A, work, info):
         M = _mat(A, 0, nb, nb, nb)
         Lf, inf = scipy.linalg.lapack.dpotrf(np.tril(M), lower=1)

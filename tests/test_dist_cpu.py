@@ -49,6 +49,40 @@ def _worker(rank, world, port, N, nb, fam, singular, out):
         dist.destroy_process_group()
 
 
+def _worker_nd(rank, world, port, N, nb, d, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SYMPGPR_NO_TORCH_PRELOAD"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympgpr_amd.dist import DistFit
+        from tests.ref_ops import RefOps
+        rng = np.random.default_rng(99)
+        X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
+        z = rng.standard_normal(2 * d * N)
+        hyp = np.append(np.full(2 * d, 1.1), 1.0)
+        f = DistFit(RefOps(), "A", None, None, z, hyp, 0.05, nb=nb, X=X)
+        out[rank] = f.run().numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_block_cyclic_two_pairs_per_point(oracle):
+    """BASELINE config 'synthetic d=2 ... 2-D block-cyclic': the distributed driver with d = 2."""
+    N, nb, d, world = 16, 4, 2, 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_nd, args=(world, _free_port(), N, nb, d, out), nprocs=world, join=True)
+    rng = np.random.default_rng(99)
+    X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
+    z = rng.standard_normal(2 * d * N)
+    a_o, _, _ = oracle.fit_nd("A", X, z, np.append(np.full(2 * d, 1.1), 1.0), 0.05)
+    for r in range(world):
+        assert np.linalg.norm(out[r] - a_o) / np.linalg.norm(a_o) < 1e-11
+
+
 def _run(world, N, nb, fam="A", singular=False):
     mgr = mp.Manager()
     out = mgr.dict()
