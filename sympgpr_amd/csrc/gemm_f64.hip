@@ -636,7 +636,7 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
     // aspect).  So: 256x128 whenever it yields >= 256 workgroups, 128x128 below.
     // SGPR_GEMM_TILE=small forces the 128x128 shape (A/B experiments).
     static const bool prefer_big = [] { const char *e = getenv("SGPR_GEMM_TILE"); return !(e && e[0] == 's'); }();
-    if (n <= 128 && m < 65536 && !(g_dbg & 8)) {
+    if (n <= 128 && m <= 32768 && !(g_dbg & 8)) {
         // one column tile (the in-place panel solve against an inverted leaf, k = n <= 128): a
         // latency problem, not a throughput one -- 64-row tiles quadruple the workgroup count and
         // halve the per-workgroup critical path (two waves, register-staged operands)
