@@ -255,6 +255,8 @@ int sgpr_probe_gemm_debug(int bits);
 /* shader cycles per phase of one 128x128 leaf factorisation: load, diag block, panel rows,
  * trailing update, write-back, inverse diag, inverse rows, final store */
 int sgpr_probe_leaf(double *out8);
+/* HW_REG_XCC_ID of each workgroup of a 1-D grid of 512-thread blocks (checks the tile map's `id % 8`) */
+int sgpr_probe_xcc(int nblocks, int *host_out);
 
 #ifdef __cplusplus
 }

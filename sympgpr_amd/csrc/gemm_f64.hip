@@ -32,7 +32,6 @@ struct ProfRec { hipEvent_t a, b; double flop; int big; int m, n, k, lower; };
 struct Prof { bool on = false; std::vector<ProfRec> recs; };
 Prof g_prof;
 int g_dbg = 0;
-int g_transb_next = 0;  // set by gemm_nn around its call
 unsigned long long *g_stamps = nullptr;  // set by gemm_set_stamps (diagnostics only)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -575,21 +574,32 @@ int gemm_nt(int m, int n, int k, double alpha, const double *A, size_t lda, cons
     return gemm_nt_bc(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, bc, st);
 }
 
+static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+                       size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc, int transb,
+                       hipStream_t st);
+
 // `bc` = {blk, pr, pi, pc, pj}: the block-cyclic form of the lower-mode skip test (GemmArgs)
 int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
                size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc,
                hipStream_t st)
+{
+    return gemm_launch(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, bc, 0, st);
+}
+
+static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B,
+                       size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc, int transb,
+                       hipStream_t st)
 {
     const bool plain = bc[0] == 1 && bc[1] == 1 && bc[3] == 1 && bc[4] == 0;
     const long diag_off = plain ? bc[2] : 1;  // != 0 disables the triangular tile enumeration
     if (bc[0] < 1 || bc[1] < 1 || bc[3] < 1) { set_error("gemm_nt: bad block-cyclic descriptor"); return SGPR_E_ARG; }
     if (m < 0 || n < 0 || k < 0) { set_error("gemm_nt: negative extent"); return SGPR_E_ARG; }
     if (m == 0 || n == 0) return 0;
-    if (lda < (size_t)m || ldb < (size_t)(g_transb_next ? k : n) || ldc < (size_t)m) {
+    if (lda < (size_t)m || ldb < (size_t)(transb ? k : n) || ldc < (size_t)m) {
         set_error("gemm: leading dimension too small");
         return SGPR_E_ARG;
     }
-    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, g_transb_next, g_stamps, 0, 0, 0, 0, 0, 0,
+    GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, transb, g_stamps, 0, 0, 0, 0, 0, 0,
                bc[0], bc[1], bc[2], bc[3], bc[4], g_dbg};
     auto set_map = [&](int bm, int bn) {
         g.tiles_m = (m + bm - 1) / bm;
@@ -662,10 +672,8 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
 int gemm_nn(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
             double beta, double *C, size_t ldc, hipStream_t st)
 {
-    g_transb_next = 1;
-    const int rc = gemm_nt(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, 0, st);
-    g_transb_next = 0;
-    return rc;
+    const int bc[5] = {1, 1, 0, 1, 0};
+    return gemm_launch(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 0, bc, 1, st);
 }
 
 void gemm_set_stamps(unsigned long long *dev_buf) { g_stamps = dev_buf; }

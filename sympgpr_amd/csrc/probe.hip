@@ -2,6 +2,7 @@
 // "verify both peaks on the box"): a register-only fp64 MFMA issue loop and a streaming
 // 16-B/lane HBM write.  Measurement aids only; nothing in the fit path calls them.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -155,9 +156,13 @@ extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
 {
     double *A = nullptr, *B = nullptr, *Cm = nullptr;
     unsigned long long *st = nullptr;
-    SGPR_HIP(hipMalloc((void **)&A, sizeof(double) * (size_t)m * k));
-    SGPR_HIP(hipMalloc((void **)&B, sizeof(double) * (size_t)n * k));
-    SGPR_HIP(hipMalloc((void **)&Cm, sizeof(double) * (size_t)m * n));
+    // leading-dimension padding (doubles) of all three operands: SGPR_PROBE_PAD, default 0
+    const char *pe = getenv("SGPR_PROBE_PAD");
+    const size_t pad = pe ? (size_t)atoi(pe) : 0;
+    const size_t lda = (size_t)m + pad, ldb = (size_t)n + pad, ldc = (size_t)m + pad;
+    SGPR_HIP(hipMalloc((void **)&A, sizeof(double) * lda * k));
+    SGPR_HIP(hipMalloc((void **)&B, sizeof(double) * ldb * k));
+    SGPR_HIP(hipMalloc((void **)&Cm, sizeof(double) * ldc * n));
     const size_t nwg = (size_t)((m + 127) / 128 + 8) * ((n + 127) / 128 + 8);
     SGPR_HIP(hipMalloc((void **)&st, sizeof(unsigned long long) * 4 * nwg));
     SGPR_HIP(hipMemset(st, 0, sizeof(unsigned long long) * 4 * nwg));
@@ -170,17 +175,17 @@ extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
     double *pts = nullptr;
     SGPR_HIP(hipMalloc((void **)&pts, sizeof(double) * h.size()));
     SGPR_HIP(hipMemcpy(pts, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
-    gram_reg(SGPR_FAM_C, m, k, pts, pts, pts + 3, pts + 5, kc, A, m, 0, 0.0, nullptr);
-    gram_reg(SGPR_FAM_C, n, k, pts, pts + 1, pts + 2, pts + 7, kc, B, n, 0, 0.0, nullptr);
-    SGPR_HIP(hipMemset(Cm, 0, sizeof(double) * (size_t)m * n));
+    gram_reg(SGPR_FAM_C, m, k, pts, pts, pts + 3, pts + 5, kc, A, lda, 0, 0.0, nullptr);
+    gram_reg(SGPR_FAM_C, n, k, pts, pts + 1, pts + 2, pts + 7, kc, B, ldb, 0, 0.0, nullptr);
+    SGPR_HIP(hipMemset(Cm, 0, sizeof(double) * ldc * n));
     hipEvent_t a, b;
     SGPR_HIP(hipEventCreate(&a));
     SGPR_HIP(hipEventCreate(&b));
-    int rc = gemm_nt(m, n, k, -1.0, A, m, B, n, 1.0, Cm, m, lower, 0, nullptr);  // warm
+    int rc = gemm_nt(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, 0, nullptr);  // warm
     if (rc) return rc;
     gemm_set_stamps(st);
     SGPR_HIP(hipEventRecord(a, nullptr));
-    rc = gemm_nt(m, n, k, -1.0, A, m, B, n, 1.0, Cm, m, lower, 0, nullptr);
+    rc = gemm_nt(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, 0, nullptr);
     SGPR_HIP(hipEventRecord(b, nullptr));
     gemm_set_stamps(nullptr);
     if (rc) return rc;
@@ -234,5 +239,28 @@ extern "C" int sgpr_probe_leaf(double *out8)
     SGPR_HIP(hipMemcpy(hs, st, 64, hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; ++i) out8[i] = (double)hs[i];
     (void)hipFree(A); (void)hipFree(inv); (void)hipFree(info); (void)hipFree(st);
+    return 0;
+}
+
+// Diagnostic: which XCD does workgroup b of a 1-D grid land on?  out[b] = HW_REG_XCC_ID of block b
+// (512-thread blocks, like the MFMA kernel).  Used to check the `id % 8` assumption of the tile map.
+namespace sgpr { namespace {
+__global__ __launch_bounds__(512) void xcc_probe_kernel(int *out)
+{
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    const int x = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    if (threadIdx.x == 0) out[blockIdx.x] = x;
+    // keep the block alive for a while so that all CUs fill up like a real launch
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < 20000) {}
+}
+} }
+extern "C" int sgpr_probe_xcc(int nblocks, int *host_out)
+{
+    int *d = nullptr;
+    SGPR_HIP(hipMalloc((void **)&d, sizeof(int) * nblocks));
+    hipLaunchKernelGGL(sgpr::xcc_probe_kernel, dim3(nblocks), dim3(512), 0, nullptr, d);
+    SGPR_HIP(hipMemcpy(host_out, d, sizeof(int) * nblocks, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
     return 0;
 }
