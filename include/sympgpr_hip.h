@@ -257,6 +257,8 @@ int sgpr_probe_gemm_debug(int bits);
 int sgpr_probe_leaf(double *out8);
 /* HW_REG_XCC_ID of each workgroup of a 1-D grid of 512-thread blocks (checks the tile map's `id % 8`) */
 int sgpr_probe_xcc(int nblocks, int *host_out);
+/* the same on a stream restricted by a CU mask (hipExtStreamCreateWithCUMask): out[2b] = XCC id, out[2b+1] = HW_ID */
+int sgpr_probe_cumask(const unsigned *mask_words, int nwords, int nblocks, int *host_out);
 
 #ifdef __cplusplus
 }

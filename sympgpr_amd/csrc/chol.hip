@@ -13,6 +13,10 @@
 // CU's 160 KiB) and then inverts in place; the inverse (LEAF x LEAF, zero upper) is kept in
 // the workspace so that every panel solve and every triangular solve below is a multiply with
 // inv(L_leaf) -- i.e. GEMM work on the matrix cores instead of a substitution.
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
 #include "common.h"
 
 namespace sgpr {
@@ -443,6 +447,74 @@ inline size_t inv_bytes(int n)
 
 size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + 256; }
 
+// Right-looking blocked factorisation with one panel of look-ahead on a side stream -- the form
+// used below ~50k, where the recursion's serial chain of leaves and small panel solves would leave
+// most of the chip idle.  Per block column k (width nb):
+//     P stream:  factor A(k,k) (recursively, leaves in LDS), solve the panel below it
+//     U stream:  U1 = update of block column k+1 only  ->  signals P to start panel k+1
+//                U2 = the rest of the trailing update (the big MFMA SYRK), runs beside panel k+1
+// Measured (factor stage, ms, recursive -> this): n = 8192 21.9 -> 16.4, 16384 66 -> 53,
+// 32768 270 -> 240, 49152 766 -> 705, 65536 1537 -> 1578 (so the recursion takes over there).
+// The overlap is partial: every CU is held by a workgroup of the big update for ~100 us at a time,
+// so the panel's short dependent kernels queue behind them (they run 2x longer than alone).
+// Reserving CUs for the panel with a CU-masked stream was tried and is slower overall (the update
+// loses 6 % of the chip and the tile map its 256-CU geometry).
+// The numbers are the same operations in a different order; the leaf workspace layout is shared with
+// the recursive driver, so the solves do not care which one produced L.
+static int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb)
+{
+    static hipStream_t sp = nullptr;
+    if (!sp) {
+        int lo = 0, hi = 0;
+        SGPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SGPR_HIP(hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, hi));
+    }
+    const int nblk = (n + nb - 1) / nb;
+    std::vector<hipEvent_t> ev(2 * (size_t)nblk + 1);
+    for (auto &e : ev) SGPR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto cleanup = [&](int rc) {
+        for (auto &e : ev) (void)hipEventDestroy(e);
+        return rc;
+    };
+    const hipStream_t su = c.st;
+    Ctx cp{c.inv, c.dinfo, sp};
+    auto panel = [&](int k) -> int {   // on the P stream
+        const int k0 = k * nb, w = std::min(nb, n - k0), below = n - k0 - w;
+        double *Akk = A + k0 + (size_t)k0 * lda;
+        int rc = potrf_rec(w, Akk, lda, k0, cp);
+        if (rc) return rc;
+        if (below > 0) rc = trsm_rec(below, w, Akk, lda, Akk + w, lda, k0, cp);
+        return rc;
+    };
+    int rc;
+    SGPR_HIP(hipEventRecord(ev[2 * nblk], su));                // the side stream joins the caller's stream ...
+    SGPR_HIP(hipStreamWaitEvent(sp, ev[2 * nblk], 0));
+    if ((rc = panel(0))) return cleanup(rc);
+    SGPR_HIP(hipEventRecord(ev[0], sp));
+    for (int k = 0; k < nblk; ++k) {
+        const int k0 = k * nb, w = std::min(nb, n - k0);
+        const int k1 = k0 + w;                                 // first row / column of block column k+1
+        SGPR_HIP(hipStreamWaitEvent(su, ev[2 * k], 0));        // panel k is ready
+        if (k1 >= n) break;
+        const int w1 = std::min(nb, n - k1), k2 = k1 + w1;
+        const double *Lk = A + (size_t)k0 * lda;               // panel k: columns k0..k0+w
+        // U1: block column k+1 (rows k1.., columns k1..k2)
+        if ((rc = gemm_nt(n - k1, w1, w, -1.0, Lk + k1, lda, Lk + k1, lda, 1.0, A + k1 + (size_t)k1 * lda, lda, 1, 0, su)))
+            return cleanup(rc);
+        SGPR_HIP(hipEventRecord(ev[2 * k + 1], su));
+        SGPR_HIP(hipStreamWaitEvent(sp, ev[2 * k + 1], 0));
+        if ((rc = panel(k + 1))) return cleanup(rc);
+        SGPR_HIP(hipEventRecord(ev[2 * (k + 1)], sp));
+        // U2: the rest of the trailing matrix (rows / columns k2..)
+        if (k2 < n &&
+            (rc = gemm_nt(n - k2, n - k2, w, -1.0, Lk + k2, lda, Lk + k2, lda, 1.0, A + k2 + (size_t)k2 * lda, lda, 1, 0, su)))
+            return cleanup(rc);
+    }
+    SGPR_HIP(hipEventRecord(ev[2 * nblk], sp));                // ... and leaves it again
+    SGPR_HIP(hipStreamWaitEvent(su, ev[2 * nblk], 0));
+    return cleanup(0);
+}
+
 int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st)
 {
     if (n < 0 || (n > 0 && lda < (size_t)n)) { set_error("potrf: bad n / lda"); return SGPR_E_ARG; }
@@ -450,7 +522,13 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     SGPR_HIP(hipMemsetAsync(dinfo, 0, sizeof(int), st));
     if (n == 0) return 0;
     Ctx c{static_cast<double *>(work), dinfo, st};
-    return potrf_rec(n, A, lda, 0, c);
+    // blocked + look-ahead for mid sizes, recursive above (measured crossover; SGPR_POTRF=rec|la overrides)
+    static const int mode = [] { const char *e = getenv("SGPR_POTRF"); return !e ? 0 : (e[0] == 'r' ? 1 : 2); }();
+    static const int nb_env = [] { const char *e = getenv("SGPR_POTRF_NB"); return e ? atoi(e) : 0; }();
+    const bool la = mode == 2 || (mode == 0 && n > 4 * LEAF && n <= 57344);
+    if (!la) return potrf_rec(n, A, lda, 0, c);
+    const int nb = nb_env > 0 ? nb_env : (n <= 8192 ? 256 : (n <= 24576 ? 512 : 1024));
+    return potrf_lookahead(n, A, lda, c, nb);
 }
 
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,

@@ -264,3 +264,29 @@ extern "C" int sgpr_probe_xcc(int nblocks, int *host_out)
     (void)hipFree(d);
     return 0;
 }
+
+// Diagnostic: where do the workgroups of a CU-masked stream run?  out[2b] = XCC id, out[2b+1] = HW_ID
+// (se/sh/cu fields) of block b, launched on a stream created with hipExtStreamCreateWithCUMask.
+namespace sgpr { namespace {
+__global__ __launch_bounds__(512) void cumask_probe_kernel(int *out)
+{
+    const int x = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+    const int hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = x; out[2 * blockIdx.x + 1] = hw; }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < 200000) {}
+}
+} }
+extern "C" int sgpr_probe_cumask(const unsigned *mask_words, int nwords, int nblocks, int *host_out)
+{
+    hipStream_t st = nullptr;
+    SGPR_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask_words));
+    int *d = nullptr;
+    SGPR_HIP(hipMalloc((void **)&d, sizeof(int) * 2 * nblocks));
+    hipLaunchKernelGGL(sgpr::cumask_probe_kernel, dim3(nblocks), dim3(512), 0, st, d);
+    SGPR_HIP(hipStreamSynchronize(st));
+    SGPR_HIP(hipMemcpy(host_out, d, sizeof(int) * 2 * nblocks, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    (void)hipStreamDestroy(st);
+    return 0;
+}

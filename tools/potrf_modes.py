@@ -1,0 +1,20 @@
+"""Factor-stage time of the recursive vs the blocked look-ahead driver: python tools/potrf_modes.py N [N...]
+(run once per mode: SGPR_POTRF=rec|la, SGPR_POTRF_NB=...)"""
+import os, sys
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "..")
+from sympgpr_amd.fit import SympFit
+from bench import synth
+for N in [int(a) for a in sys.argv[1:]]:
+    q, P, z, hyp, s2 = synth(N)
+    with SympFit("A", q, P, z, hyp, s2, lower_only=False) as f:
+        f.run()
+        ts = []
+        for _ in range(3):
+            f.build(); f.factor(); ts.append(f.stage_ms()[1])
+        f.solve(); a = f.alpha()
+        op, oq = f.predict_rows(q[:256], P[:256])
+        r = np.concatenate([op + s2 * a[:256] - z[:256], oq + s2 * a[N:N + 256] - z[N:N + 256]])
+    n = 2 * N
+    print("mode=%s nb=%s n=%d: factor %.2f ms = %.2f TFLOP/s  resid %.1e" % (os.environ.get("SGPR_POTRF"), os.environ.get("SGPR_POTRF_NB"),
+          n, min(ts), n**3 / 3 / min(ts) / 1e9, np.linalg.norm(r) / np.linalg.norm(z[:512])))
