@@ -463,12 +463,16 @@ size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + 256; }
 // the recursive driver, so the solves do not care which one produced L.
 static int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb)
 {
-    static hipStream_t sp = nullptr;
-    if (!sp) {
+    static hipStream_t side[64] = {};          // one side stream per device, created on first use
+    int dev = 0;
+    SGPR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
+    if (!side[dev]) {
         int lo = 0, hi = 0;
         SGPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        SGPR_HIP(hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, hi));
+        SGPR_HIP(hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi));
     }
+    const hipStream_t sp = side[dev];
     const int nblk = (n + nb - 1) / nb;
     std::vector<hipEvent_t> ev(2 * (size_t)nblk + 1);
     for (auto &e : ev) SGPR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
