@@ -104,7 +104,7 @@ def main():
                     help="canonical pairs per training point (matrix order n = 2*d*N); 1 = the reference's "
                          "(q, P) layout, 2 / 3 = BASELINE configs 03_henon_heiles / 05_tokamak")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--nb", type=int, default=1024, help="block size of the multi-GPU block-cyclic layout")
+    ap.add_argument("--nb", type=int, default=2048, help="block size of the multi-GPU block-cyclic layout")
     ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="skip the per-launch HIP-event timing of the GEMM kernel (use under rocprofv3 --pmc)")
