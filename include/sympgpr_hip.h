@@ -42,7 +42,10 @@ enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/ke
        SGPR_FAM_D = 3 }; /* periodic, free period p      : 01_pendulum/implicit_period_unknown/kernels.f90 */
 
 /* `which` of sgpr_kernel_eval: the four functions of a kernels*.f90 that enter K */
-enum { SGPR_K_KERN = 0, SGPR_K_DXDX0 = 1, SGPR_K_DYDY0 = 2, SGPR_K_DXDY0 = 3 };
+enum { SGPR_K_KERN = 0, SGPR_K_DXDX0 = 1, SGPR_K_DYDY0 = 2, SGPR_K_DXDY0 = 3,
+       /* OR-ed in: the derivative of that function with respect to lx / ly (dkdlx_num,
+        * d3kdxdx0dlx_num, ... kernels.f90:133-231; product kernels only) */
+       SGPR_K_DLX = 4, SGPR_K_DLY = 8 };
 
 enum { SGPR_E_ARG = -1, SGPR_E_NODEVICE = -2, SGPR_E_HIP = -3, SGPR_E_NOMEM = -4,
        SGPR_E_STATE = -5 };
@@ -57,7 +60,9 @@ enum { SGPR_G_QQ = 1, SGPR_G_PQ = 2, SGPR_G_QP = 4, SGPR_G_PP = 8, SGPR_G_ALL = 
 /* fit flags */
 enum { SGPR_FIT_LOWER_ONLY = 1,  /* build only the lower triangle (what the factor reads)   */
        SGPR_FIT_KEEP_K = 2,      /* keep an untouched copy of Ky next to L (2x memory)       */
-       SGPR_FIT_REG = 4 };       /* scalar-kernel GP (buildKreg, n = n_pts): nll_chol_reg     */
+       SGPR_FIT_REG = 4,         /* scalar-kernel GP (buildKreg, n = n_pts): nll_chol_reg     */
+       SGPR_FIT_BLOCK_QQ = 8,    /* only the qq block of build_K (n = n_pts): nll_expl ind=0,  */
+       SGPR_FIT_BLOCK_PP = 16 }; /* only the PP block, ind=1 (04_standard_map/func.py:126-141) */
 
 int sgpr_abi_version(void);
 const char *sgpr_last_error(void);
@@ -103,6 +108,10 @@ int sgpr_build_dkreg_host(int family, int which, int n, int n0, const double *x,
 int sgpr_potrf_host(int n, double *A, size_t lda);
 /* solve_cholesky(L, B) (func.py:174-177): B (n x nrhs) overwritten by L^-T L^-1 B. */
 int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, int nrhs);
+/* LAPACK dsyev('V','L')-shaped: A (n x n column-major host buffer, lower triangle read) is
+ * overwritten by the eigenvectors, w (n) gets the eigenvalues ascending -- the dense equivalent
+ * of the drivers' `eigsh(Ky, neig)` fallback (02_pert_pendulum/func.py:199). */
+int sgpr_syev_host(int n, double *A, size_t lda, double *w);
 
 /* ---- device-resident fit: the whole nll_chol path without K ever leaving HBM --------------
  * replaces python/functions/func.py:189-196 (nll_chol) / :165-171 (gpsolve) on (x, x). */
@@ -146,6 +155,18 @@ int sgpr_fit_inverse(sgpr_fit_t f, double *Kyinv, size_t ld);
 /* gradient of the nll with respect to (lx, ly) on a solved fit: what nll_grad / nll_grad_reg
  * return as nlp_grad (functions/func.py:132-162) */
 int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2);
+/* the pieces the per-example nll_grad variants recombine (03_henon_heiles/func.py:168-192,
+ * 05_tokamak/SympGPR/func.py:152-168 add a third component from dK/dsig = K / sig):
+ * terms5 = [alpha^T dK_lx alpha, tr(Ky^-1 dK_lx), alpha^T dK_ly alpha, tr(Ky^-1 dK_ly), tr(Ky^-1)] */
+int sgpr_fit_nll_grad_terms(sgpr_fit_t f, double *terms5);
+/* Eigen-decomposition of Ky = K + |sig2n| I on the device (parallel cyclic Jacobi): the
+ * positive-definiteness FAILURE path of the drivers' nll_chol, which falls back to
+ * `eigsh(Ky, neig, ...)` when cholesky raises (02_pert_pendulum/func.py:194-203,
+ * 01_pendulum/implicit/func.py:99-114, 05_tokamak/Split_SympGPR/func.py:128-166).  Ky is rebuilt
+ * (a failed factor has overwritten it) and diagonalised in place; w (n) = eigenvalues ascending,
+ * c (n) = Q^T z.  The fit has to be built / run again before any other query.
+ * Returns 0, or 1 if the rotations did not converge. */
+int sgpr_fit_eig(sgpr_fit_t f, double *w, double *c);
 /* K* . alpha for m test points with d pairs each: Xt (m x 2d), out (m x 2d), both column-major */
 int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, double *out);
 /* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
@@ -220,13 +241,23 @@ int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, in
 /* applymap / applymap_henon (functions/func.py:216-260; calcP / calcQ / guessP of sympgpr.f90:62-125
  * inlined) for all Ntest orbits with every time step on the device: one workgroup per orbit, the
  * implicit equation for P solved by a secant iteration from the regular-GP guess (tol 1e-13 like
- * hybrd1), q optionally wrapped mod 2 pi.  alpha = Kyinv ztrain, alphap = Kyinvp ztrainp.
- * qmap, pmap: [nm][ntest] C-ordered; a NaN marks a lost orbit from that step on. */
-int sgpr_applymap_host(int family, int wrap, int nm, int ntest, const double *hyp, int nhyp, int n0,
+ * hybrd1).  alpha = Kyinv ztrain, alphap = Kyinvp ztrainp.
+ * mode bits select the per-example variants of the same recurrence:
+ *   SGPR_MAP_WRAP_Q    q mod 2 pi                 (applymap; not applymap_henon, func.py:239-260)
+ *   SGPR_MAP_WRAP_P    P mod 2 pi before the q update (04_standard_map/func.py:218-254)
+ *   SGPR_MAP_EXPLICIT  P = p - Kstar(1,:).alpha at (q, p), no implicit solve and no first-guess GP
+ *                      (01_pendulum/explicit/func_expl.py:106-128, 04_standard_map/func.py:174-179,
+ *                      256-285); hypp / xtrainp / ytrainp / alphap are ignored
+ * qmap, pmap: [nm][ntest] C-ordered; a NaN marks a lost orbit from that step on.  pdiff (may be
+ * NULL): the unwrapped momentum, pdiff[i+1] = pdiff[i] + (P_new - p_i) (04_standard_map/func.py:234). */
+#define SGPR_MAP_WRAP_Q 1
+#define SGPR_MAP_WRAP_P 2
+#define SGPR_MAP_EXPLICIT 4
+int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hyp, int nhyp, int n0,
                        const double *xtrain, const double *ytrain, const double *alpha,
                        const double *hypp, int nhypp, int n0p, const double *xtrainp,
                        const double *ytrainp, const double *alphap, const double *Q0,
-                       const double *P0, double *qmap, double *pmap);
+                       const double *P0, double *qmap, double *pmap, double *pdiff);
 /* alpha-solve on device with the factor and its leaf inverses: b (n) := L^-T L^-1 b */
 int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b,
                        void *stream);

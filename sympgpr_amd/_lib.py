@@ -6,8 +6,10 @@ import numpy as np
 
 FAMILIES = {"A": 0, "B": 1, "C": 2, "D": 3}
 K_KERN, K_DXDX0, K_DYDY0, K_DXDY0 = 0, 1, 2, 3
+K_DLX, K_DLY = 4, 8
 G_QQ, G_PQ, G_QP, G_PP, G_ALL, G_LOWER, G_OCML, G_DLX, G_DLY = 1, 2, 4, 8, 15, 16, 32, 64, 128
-FIT_LOWER_ONLY, FIT_KEEP_K, FIT_REG = 1, 2, 4
+FIT_LOWER_ONLY, FIT_KEEP_K, FIT_REG, FIT_BLOCK_QQ, FIT_BLOCK_PP = 1, 2, 4, 8, 16
+MAP_WRAP_Q, MAP_WRAP_P, MAP_EXPLICIT = 1, 2, 4
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -60,6 +62,9 @@ SIGNATURES = {
     "sgpr_fit_solve_rhs": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
     "sgpr_fit_predict_rows": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "sgpr_fit_nll_grad": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_nll_grad_terms": (C.c_int, [_vp, _dp]),
+    "sgpr_fit_eig": (C.c_int, [_vp, _dp, _dp]),
+    "sgpr_syev_host": (C.c_int, [C.c_int, _dp, C.c_size_t, _dp]),
     "sgpr_fit_inverse": (C.c_int, [_vp, _dp, C.c_size_t]),
     "sgpr_fit_predict_nd": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t, _dp]),
     "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
@@ -97,7 +102,7 @@ SIGNATURES = {
                                       _vp, _vp, _vp]),
     "sgpr_predict_reg_dev": (C.c_int, [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp]),
     "sgpr_applymap_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
-                                     C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+                                     C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
 }
 

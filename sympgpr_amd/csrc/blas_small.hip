@@ -76,6 +76,20 @@ __global__ __launch_bounds__(256) void dot_kernel(int n, const double *a, size_t
     if (threadIdx.x == 0) out[0] = sq[0] + sq[1] + sq[2] + sq[3];
 }
 
+// sum of squares, two deterministic passes: per-workgroup partials, then one workgroup over them
+constexpr int SS_WG = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(size_t count, const double *a, double *part)
+{
+    double q = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256)
+        q = __builtin_fma(a[i], a[i], q);
+    __shared__ double sq[4];
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_down(q, o, 64);
+    if ((threadIdx.x & 63) == 0) sq[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sq[0] + sq[1] + sq[2] + sq[3];
+}
+
 __global__ void transpose_kernel(int m, int n, const double *A, size_t lda, double *B, size_t ldb)
 {
     __shared__ double tile[32][33];
@@ -189,6 +203,17 @@ int copy_diag(int n, const double *A, size_t lda, double *d, hipStream_t st)
 int dot(int n, const double *a, const double *b, double *out, hipStream_t st)
 {
     hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, n, a, (size_t)1, b, out);
+    SGPR_CHECK_LAUNCH();
+    return 0;
+}
+
+// part: device scratch of SUMSQ_SCRATCH doubles
+int sumsq(size_t count, const double *a, double *part, double *out, hipStream_t st)
+{
+    static_assert(SS_WG == SUMSQ_SCRATCH, "scratch size");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SS_WG), dim3(256), 0, st, count, a, part);
+    SGPR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, st, SS_WG, part, (size_t)1, (const double *)nullptr, out);
     SGPR_CHECK_LAUNCH();
     return 0;
 }

@@ -328,10 +328,15 @@ static int fit_create_common(int family, int d, int n_pts, const double *X, size
     if (!out || n_pts <= 0 || (d == 1 ? (!x || !y) : !X)) { set_error("fit_create: bad arguments"); return SGPR_E_ARG; }
     if (flags & SGPR_FIT_KEEP_K) { set_error("fit_create: SGPR_FIT_KEEP_K not implemented"); return SGPR_E_ARG; }
     if (d != 1 && (flags & SGPR_FIT_REG)) { set_error("fit_create: the scalar-kernel GP exists for d = 1 only"); return SGPR_E_ARG; }
+    const unsigned single = flags & (SGPR_FIT_REG | SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP);
+    if ((single & (single - 1)) || (d != 1 && single)) {
+        set_error("fit_create: SGPR_FIT_REG / BLOCK_QQ / BLOCK_PP are mutually exclusive and need d = 1");
+        return SGPR_E_ARG;
+    }
     sgpr_fit *f = new (std::nothrow) sgpr_fit;
     if (!f) return SGPR_E_NOMEM;
     f->family = family; f->npts = n_pts; f->d = d; f->flags = flags;
-    f->n = (flags & SGPR_FIT_REG) ? n_pts : 2 * d * n_pts;
+    f->n = single ? n_pts : 2 * d * n_pts;
     f->st = static_cast<hipStream_t>(stream);
     if (d == 1) {
         if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
@@ -416,13 +421,13 @@ int sgpr_fit_set_targets(sgpr_fit_t f, const double *z)
     return 0;
 }
 
-int sgpr_fit_build(sgpr_fit_t f)
+static int fit_build_impl(sgpr_fit_t f, bool lower_only)
 {
     if (!f) { set_error("null fit"); return SGPR_E_ARG; }
     const size_t n = (size_t)f->n;
     const int N = f->npts;
     unsigned flags = SGPR_G_ALL;
-    if (f->flags & SGPR_FIT_LOWER_ONLY) flags |= SGPR_G_LOWER;
+    if (lower_only) flags |= SGPR_G_LOWER;
     SGPR_HIP(hipEventRecord(f->ev[0], f->st));
     int rc;
     if (f->d > 1) {
@@ -432,6 +437,11 @@ int sgpr_fit_build(sgpr_fit_t f)
     } else if (f->flags & SGPR_FIT_REG) {
         // Ky = buildKreg(x, x) + |sig2n| I  (func.py:182-183)
         rc = gram_reg(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, n, 0, std::fabs(f->sig2n), f->st);
+    } else if (f->flags & (SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP)) {
+        // one diagonal block of build_K(x, x) + |sig2n| I  (04_standard_map/func.py:126-135)
+        const unsigned part = (f->flags & SGPR_FIT_BLOCK_QQ) ? SGPR_G_QQ : SGPR_G_PP;
+        rc = gram_pairs(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, f->dA, f->dA, f->dA, n, 0,
+                        std::fabs(f->sig2n), part | (flags & SGPR_G_LOWER), f->st);
     } else
     // Ky = build_K(x, x) + |sig2n| I  (func.py:191-192), noise fused into the diagonal tiles
     rc = gram_pairs(f->family, N, N, f->dx, f->dy, f->dx, f->dy, f->kc, f->dA, f->dA + N,
@@ -442,6 +452,61 @@ int sgpr_fit_build(sgpr_fit_t f)
     f->built = true;
     f->factored = f->solved = false;
     return 0;
+}
+
+int sgpr_fit_build(sgpr_fit_t f) { return fit_build_impl(f, f && (f->flags & SGPR_FIT_LOWER_ONLY)); }
+
+/* Eigen-decomposition of Ky = K + |sig2n| I on the device (parallel cyclic Jacobi, eig.hip): the
+ * positive-definiteness failure path of the drivers' nll_chol, which falls back to
+ * `eigsh(Ky, neig, ...)` when cholesky raises (02_pert_pendulum/func.py:194-203).  Ky is rebuilt
+ * (a failed factorisation has overwritten it), diagonalised in place, and
+ * w (n, ascending eigenvalues) and c = Q^T z (n) come back; the caller forms
+ * alpha = Q diag(1/w) c and the log-determinant from whichever eigenpairs it keeps.
+ * Two n x n matrices in HBM.  Returns 0, or 1 if the rotations did not converge in 40 sweeps. */
+int sgpr_fit_eig(sgpr_fit_t f, double *w, double *c)
+{
+    if (!f || !w || !c) { set_error("null argument"); return SGPR_E_ARG; }
+    int rc = fit_build_impl(f, false);
+    if (rc) return rc;
+    const size_t n = (size_t)f->n;
+    DevBuf V, tmp;
+    if ((rc = V.alloc(n * n * sizeof(double))) || (rc = tmp.alloc(n * sizeof(double)))) return rc;
+    int sweeps = 0;
+    const int st = syev_jacobi(f->n, f->dA, n, V.as<double>(), n, w, 40, &sweeps, f->st);
+    f->built = f->factored = f->solved = false;   // dA now holds the eigenvectors
+    if (st < 0) return st;
+    SGPR_HIP(hipMemsetAsync(tmp.p, 0, n * sizeof(double), f->st));
+    if ((rc = gemv_t_sub(f->n, f->n, f->dA, n, f->dz, tmp.as<double>(), f->st))) return rc;   // tmp = -Q^T z
+    SGPR_HIP(hipMemcpyAsync(c, tmp.p, n * sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    for (size_t i = 0; i < n; ++i) c[i] = -c[i];
+    if (st > 0) set_error("fit_eig: Jacobi sweeps did not converge");
+    return st;
+}
+
+/* LAPACK dsyev('V', 'L') shaped host call: A (n x n, column-major, lower triangle read) is
+ * overwritten by the eigenvectors, w (n) receives the eigenvalues in ascending order. */
+int sgpr_syev_host(int n, double *A, size_t lda, double *w)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!A || !w || lda < (size_t)n))) { set_error("syev: bad arguments"); return SGPR_E_ARG; }
+    if (n == 0) return 0;
+    const size_t N = (size_t)n;
+    DevBuf dA, dV;
+    if ((rc = dA.alloc(N * N * sizeof(double))) || (rc = dV.alloc(N * N * sizeof(double)))) return rc;
+    hipStream_t st = nullptr;
+    SGPR_HIP(hipMemcpy2DAsync(dA.p, N * sizeof(double), A, lda * sizeof(double), N * sizeof(double), N,
+                              hipMemcpyHostToDevice, st));
+    if ((rc = sym_fill_upper(n, dA.as<double>(), N, st))) return rc;
+    int sweeps = 0;
+    const int status = syev_jacobi(n, dA.as<double>(), N, dV.as<double>(), N, w, 40, &sweeps, st);
+    if (status < 0) return status;
+    SGPR_HIP(hipMemcpy2DAsync(A, lda * sizeof(double), dA.p, N * sizeof(double), N * sizeof(double), N,
+                              hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    if (status > 0) set_error("syev: Jacobi sweeps did not converge");
+    return status;
 }
 
 int sgpr_fit_factor(sgpr_fit_t f)
@@ -563,6 +628,7 @@ int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P,
     if (!f || m < 0 || !q || !P || !out_p || !out_q) { set_error("fit_predict_rows: bad arguments"); return SGPR_E_ARG; }
     if (!f->solved) { set_error("fit_predict_rows: not solved"); return SGPR_E_STATE; }
     if (f->d > 1) { set_error("fit_predict_rows: use sgpr_fit_predict_nd for d > 1"); return SGPR_E_STATE; }
+    if (f->flags & (SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP)) { set_error("fit_predict_rows: not defined for a single-block fit"); return SGPR_E_STATE; }
     if (m == 0) return 0;
     DevBuf dq, dP, dop, doq;
     int rc;
@@ -613,11 +679,12 @@ int sgpr_fit_inverse(sgpr_fit_t f, double *Kyinv, size_t ld)
  * The reference forms Ky^-1 explicitly; here tr(Ky^-1 dK) = tr(L^-1 dK L^-T): W = dK, W := W L^-T
  * (panel solve), W := W^T (= L^-1 dK by symmetry), W := W L^-T again, sum of the diagonal --
  * 2 n^3 flop per length scale on the MFMA kernel, two n x n scratch matrices. */
-int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2)
+static int nll_grad_core(sgpr_fit_t f, double *h)
 {
-    if (!f || !grad2) { set_error("null argument"); return SGPR_E_ARG; }
+    if (!f || !h) { set_error("null argument"); return SGPR_E_ARG; }
     if (!f->solved) { set_error("fit_nll_grad: run the fit first"); return SGPR_E_STATE; }
     if (f->d > 1) { set_error("fit_nll_grad: available for d = 1"); return SGPR_E_STATE; }
+    if (f->flags & (SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP)) { set_error("fit_nll_grad: not defined for a single-block fit"); return SGPR_E_STATE; }
     const size_t n = (size_t)f->n;
     const int N = f->npts;
     DevBuf W, T, tmp, sc;
@@ -644,10 +711,47 @@ int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2)
         if ((rc = trsm_rlt(f->n, f->n, f->dA, n, t, n, f->work, f->st))) return rc;
         if ((rc = trace(f->n, t, n, s + 2 * which + 1, f->st))) return rc;
     }
-    double h[4];
     SGPR_HIP(hipMemcpyAsync(h, s, 4 * sizeof(double), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
-    for (int which = 0; which < 2; ++which) grad2[which] = -0.5 * (-h[2 * which]) + 0.5 * h[2 * which + 1];
+    h[0] = -h[0];   // the GEMV helper subtracts: s[0], s[2] hold -(alpha^T dK alpha)
+    h[2] = -h[2];
+    return 0;
+}
+
+int sgpr_fit_nll_grad(sgpr_fit_t f, double *grad2)
+{
+    if (!grad2) { set_error("null argument"); return SGPR_E_ARG; }
+    double h[4];
+    int rc = nll_grad_core(f, h);
+    if (rc) return rc;
+    for (int which = 0; which < 2; ++which) grad2[which] = -0.5 * h[2 * which] + 0.5 * h[2 * which + 1];
+    return 0;
+}
+
+/* The pieces the per-example nll_grad variants recombine (03_henon_heiles/func.py:168-192,
+ * 05_tokamak/SympGPR/func.py:152-168: a third component built from dK/dsig = K / sig):
+ * terms5 = [alpha^T dK_lx alpha, tr(Ky^-1 dK_lx), alpha^T dK_ly alpha, tr(Ky^-1 dK_ly), tr(Ky^-1)].
+ * tr(Ky^-1) = ||L^-1||_F^2 from a panel solve on the identity. */
+int sgpr_fit_nll_grad_terms(sgpr_fit_t f, double *terms5)
+{
+    if (!terms5) { set_error("null argument"); return SGPR_E_ARG; }
+    int rc = nll_grad_core(f, terms5);
+    if (rc) return rc;
+    const size_t n = (size_t)f->n;
+    DevBuf W, sc;
+    if ((rc = W.alloc(n * n * sizeof(double))) || (rc = sc.alloc((SUMSQ_SCRATCH + 1) * sizeof(double)))) return rc;
+    double *w = W.as<double>();
+    SGPR_HIP(hipMemsetAsync(w, 0, n * n * sizeof(double), f->st));
+    {
+        std::vector<double> ones(n, 1.0);
+        SGPR_HIP(hipMemcpy2DAsync(w, (n + 1) * sizeof(double), ones.data(), sizeof(double), sizeof(double), n,
+                                  hipMemcpyHostToDevice, f->st));
+        SGPR_HIP(hipStreamSynchronize(f->st));
+    }
+    if ((rc = trsm_rlt(f->n, f->n, f->dA, n, w, n, f->work, f->st))) return rc;            // W = L^-T
+    if ((rc = sumsq(n * n, w, sc.as<double>() + 1, sc.as<double>(), f->st))) return rc;
+    SGPR_HIP(hipMemcpyAsync(terms5 + 4, sc.p, sizeof(double), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
     return 0;
 }
 
@@ -819,33 +923,46 @@ int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, in
     return predict_reg(family, m, q, P, n0, xtrain, ytrain, kc, alpha, out, static_cast<hipStream_t>(stream));
 }
 
-/* applymap / applymap_henon (functions/func.py:216-260) for all Ntest orbits, every time step on
- * the device.  alpha = Kyinv ztrain (2 n0), alphap = Kyinvp ztrainp (n0p); qmap, pmap: [nm][ntest]
- * C-ordered host arrays (row 0 = initial conditions).  wrap != 0: q mod 2 pi. */
-int sgpr_applymap_host(int family, int wrap, int nm, int ntest, const double *hyp, int nhyp, int n0,
+/* applymap / applymap_henon (functions/func.py:216-260) and the per-example variants for all Ntest
+ * orbits, every time step on the device.  alpha = Kyinv ztrain (2 n0), alphap = Kyinvp ztrainp (n0p);
+ * qmap, pmap, pdiff: [nm][ntest] C-ordered host arrays (row 0 = initial conditions), pdiff optional.
+ * mode: SGPR_MAP_* bits. */
+int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hyp, int nhyp, int n0,
                        const double *xtrain, const double *ytrain, const double *alpha, const double *hypp,
                        int nhypp, int n0p, const double *xtrainp, const double *ytrainp, const double *alphap,
-                       const double *Q0, const double *P0, double *qmap, double *pmap)
+                       const double *Q0, const double *P0, double *qmap, double *pmap, double *pdiff)
 {
     int rc = need_device();
     if (rc) return rc;
-    if (nm < 1 || ntest < 0 || n0 < 0 || n0p < 0) { set_error("applymap: bad arguments"); return SGPR_E_ARG; }
-    KConst kc, kcp;
-    if ((rc = make_kconst(family, hyp, nhyp, &kc)) || (rc = make_kconst(family, hypp, nhypp, &kcp))) return rc;
+    const bool expl = (mode & SGPR_MAP_EXPLICIT) != 0;
+    if (expl) n0p = 0;                       /* no first-guess GP in the explicit map */
+    if (nm < 1 || ntest < 0 || n0 < 0 || n0p < 0 || (mode & ~7) || !qmap || !pmap) {
+        set_error("applymap: bad arguments");
+        return SGPR_E_ARG;
+    }
+    KConst kc, kcp{};
+    if ((rc = make_kconst(family, hyp, nhyp, &kc))) return rc;
+    if (!expl && (rc = make_kconst(family, hypp, nhypp, &kcp))) return rc;
     if (ntest == 0) return 0;
-    DevBuf x, y, al, xp, yp, alp, q0, p0, qm, pm;
+    if (!Q0 || !P0 || (n0 > 0 && (!xtrain || !ytrain || !alpha)) || (n0p > 0 && (!xtrainp || !ytrainp || !alphap))) {
+        set_error("applymap: null argument");
+        return SGPR_E_ARG;
+    }
+    DevBuf x, y, al, xp, yp, alp, q0, p0, qm, pm, pd;
     hipStream_t st = nullptr;
+    const size_t out_bytes = (size_t)nm * ntest * sizeof(double);
     if ((rc = upload(x, xtrain, n0, st)) || (rc = upload(y, ytrain, n0, st)) || (rc = upload(al, alpha, 2 * (size_t)n0, st)) ||
         (rc = upload(xp, xtrainp, n0p, st)) || (rc = upload(yp, ytrainp, n0p, st)) || (rc = upload(alp, alphap, n0p, st)) ||
-        (rc = upload(q0, Q0, ntest, st)) || (rc = upload(p0, P0, ntest, st)) ||
-        (rc = qm.alloc((size_t)nm * ntest * sizeof(double))) || (rc = pm.alloc((size_t)nm * ntest * sizeof(double))))
+        (rc = upload(q0, Q0, ntest, st)) || (rc = upload(p0, P0, ntest, st)) || (rc = qm.alloc(out_bytes)) ||
+        (rc = pm.alloc(out_bytes)) || (pdiff && (rc = pd.alloc(out_bytes))))
         return rc;
-    rc = applymap(family, wrap, nm, ntest, n0, x.as<double>(), y.as<double>(), kc, al.as<double>(), n0p,
+    rc = applymap(family, mode, nm, ntest, n0, x.as<double>(), y.as<double>(), kc, al.as<double>(), n0p,
                   xp.as<double>(), yp.as<double>(), kcp, alp.as<double>(), q0.as<double>(), p0.as<double>(),
-                  qm.as<double>(), pm.as<double>(), st);
+                  qm.as<double>(), pm.as<double>(), pdiff ? pd.as<double>() : nullptr, st);
     if (rc) return rc;
-    SGPR_HIP(hipMemcpyAsync(qmap, qm.p, (size_t)nm * ntest * sizeof(double), hipMemcpyDeviceToHost, st));
-    SGPR_HIP(hipMemcpyAsync(pmap, pm.p, (size_t)nm * ntest * sizeof(double), hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipMemcpyAsync(qmap, qm.p, out_bytes, hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipMemcpyAsync(pmap, pm.p, out_bytes, hipMemcpyDeviceToHost, st));
+    if (pdiff) SGPR_HIP(hipMemcpyAsync(pdiff, pd.p, out_bytes, hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipStreamSynchronize(st));
     return 0;
 }

@@ -52,10 +52,10 @@ int predict_reg(int family, int m, const double *q, const double *P, int n0, con
                 const double *ytr, const KConst &kc, const double *alpha, double *out,
                 hipStream_t st);
 
-int applymap(int family, int wrap, int nm, int ntest, int n0, const double *xtr, const double *ytr,
+int applymap(int family, int mode, int nm, int ntest, int n0, const double *xtr, const double *ytr,
              const KConst &kc, const double *alpha, int n0p, const double *xtrp, const double *ytrp,
              const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
-             double *pmap, hipStream_t st);
+             double *pmap, double *pdiff, hipStream_t st);
 
 // ---- gram_nd.hip : d canonical pairs per point (X: points x 2d, column-major)
 int gram_nd(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa, size_t ldxa,
@@ -100,6 +100,11 @@ int nll_reduce(int n, const double *L, size_t ldl, const double *z, const double
                double *dout /* [0]=0.5 z.alpha + sum log diag */, hipStream_t st);
 int copy_diag(int n, const double *A, size_t lda, double *d, hipStream_t st);
 int dot(int n, const double *a, const double *b, double *out, hipStream_t st);      // out[0] = a.b
+constexpr int SUMSQ_SCRATCH = 1024;
+// ---- eig.hip
+int syev_jacobi(int n, double *A, size_t lda, double *V, size_t ldv, double *w_host, int max_sweeps,
+                int *sweeps_done, hipStream_t st);
+int sumsq(size_t count, const double *a, double *part, double *out, hipStream_t st);
 int trace(int n, const double *A, size_t lda, double *out, hipStream_t st);          // out[0] = sum A_ii
 int transpose(int m, int n, const double *A, size_t lda, double *B, size_t ldb, hipStream_t st);
 int gemv_n_sub(int m, int k, const double *A, size_t lda, const double *x, double *y,

@@ -85,7 +85,7 @@ __device__ __forceinline__ void pair_eval(double xa, double ya, double xb, doubl
 }
 
 // d/dlx (DL = 1) or d/dly (DL = 2) of the three Hessian entries: the third-derivative kernels
-// d3kd..dl._num of kernels.f90:155-231 / kernels_sq.f90:146-217 in factored form.  With
+// d3kd..dl._num of kernels.f90:133-231 / kernels_sq.f90:146-217 in factored form.  With
 // E = exp(-u/2lx^2 - v/2ly^2), u = sin^2 h (A, D) or dx^2 (C), v = dy^2:
 //   d(g(l) E)/dlx = g'(lx) E + g E u/lx^3,   d(.)/dly = ... + g E v/ly^3.
 template <int FAM, int DL>
@@ -310,8 +310,9 @@ __global__ __launch_bounds__(GT) void gram_reg_kernel(const RegArgs a)
     }
 }
 
-// kernels.<name>_num, elementwise (sig = 1)
-template <int FAM>
+// kernels.<name>_num, elementwise (sig = 1).  DL selects the length-scale derivative family
+// (dkdlx_num, d3kdxdx0dlx_num, ... kernels.f90:133-231).
+template <int FAM, int DL>
 __global__ void kernel_eval_kernel(int which, int m, const double *xa, const double *ya,
                                    const double *xb, const double *yb, const KConst kc, double *out)
 {
@@ -319,10 +320,10 @@ __global__ void kernel_eval_kernel(int which, int m, const double *xa, const dou
     if (i >= m) return;
     double r;
     if (which == SGPR_K_KERN) {
-        r = kern_eval<FAM, false>(xa[i], ya[i], xb[i], yb[i], kc);
+        r = kern_any<FAM, false, DL>(xa[i], ya[i], xb[i], yb[i], kc);
     } else {
         double kxx, kxy, kyy;
-        pair_eval<FAM, false>(xa[i], ya[i], xb[i], yb[i], kc, kxx, kxy, kyy);
+        pair_any<FAM, false, DL>(xa[i], ya[i], xb[i], yb[i], kc, kxx, kxy, kyy);
         r = which == SGPR_K_DXDX0 ? kxx : (which == SGPR_K_DYDY0 ? kyy : kxy);
     }
     out[i] = r;
@@ -397,12 +398,12 @@ __global__ __launch_bounds__(GT) void predict_reg_kernel(int n0, const double *q
 // residual an O(n^2) matmul with Kyinv); here alpha = Kyinv ztrain is cached, a residual is one
 // block-wide reduction over the training points, and all nm steps run without leaving the GPU.
 struct MapArgs {
-    int nm, ntest, n0, n0p, wrap, maxiter;
+    int nm, ntest, n0, n0p, mode, maxiter;
     double tol;
     const double *xtr, *ytr, *alpha;      // symplectic GP: n0 points, alpha 2 n0
     const double *xtrp, *ytrp, *alphap;   // regular GP (guess): n0p points
     const double *Q0, *P0;
-    double *qmap, *pmap;                  // [nm][ntest], C order (numpy zeros([nm, Ntest]))
+    double *qmap, *pmap, *pdiff;          // [nm][ntest], C order (numpy zeros([nm, Ntest])); pdiff may be null
     KConst kc, kcp;
 };
 
@@ -445,37 +446,59 @@ __global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
         block_sum2(r, z, sh);
         return r;
     };
-    double q = a.Q0[k], p = a.P0[k];
-    if (threadIdx.x == 0) { a.qmap[k] = q; a.pmap[k] = p; }
+    double q = a.Q0[k], p = a.P0[k], pd = p;
+    if (threadIdx.x == 0) {
+        a.qmap[k] = q;
+        a.pmap[k] = p;
+        if (a.pdiff) a.pdiff[k] = pd;
+    }
     const double nan = __builtin_nan("");
+    const double twopi = 6.283185307179586477;
     for (int i = 0; i + 1 < a.nm; ++i) {
-        double qn = nan, pn = nan;
+        double qn = nan, pn = nan, pdn = nan;
         if (!(q != q) && !(p != p)) {                      // NaN = lost orbit stays lost (func.py:231-232)
-            double P0 = guess(q, p), r1, r2;
-            rows(q, P0, r1, r2);
-            double f0 = r1 - p + P0;
-            double P1 = P0 - f0;                            // f'(P) ~ 1 near the identity map
-            rows(q, P1, r1, r2);
-            double f1 = r1 - p + P1;
-            for (int it = 0; it < a.maxiter; ++it) {        // secant; every quantity is block-uniform
-                if (!(fabs(P1 - P0) > a.tol * fmax(1.0, fabs(P1))) || !(f1 == f1)) break;
-                const double d = f1 - f0;
-                if (d == 0.0) break;
-                const double Pn = P1 - f1 * (P1 - P0) / d;
-                P0 = P1; f0 = f1; P1 = Pn;
+            double r1, r2, Praw = nan;
+            bool have_r2 = false;
+            if (a.mode & SGPR_MAP_EXPLICIT) {
+                // explicit map (01_pendulum/explicit/func_expl.py:106-119, 04_standard_map/func.py:174-179):
+                // P = p - Kstar(1,:).alpha at (q, p), no implicit equation
+                rows(q, p, r1, r2);
+                Praw = p - r1;
+            } else {
+                double P0 = guess(q, p);
+                rows(q, P0, r1, r2);
+                double f0 = r1 - p + P0;
+                double P1 = P0 - f0;                            // f'(P) ~ 1 near the identity map
                 rows(q, P1, r1, r2);
-                f1 = r1 - p + P1;
+                double f1 = r1 - p + P1;
+                for (int it = 0; it < a.maxiter; ++it) {        // secant; every quantity is block-uniform
+                    if (!(fabs(P1 - P0) > a.tol * fmax(1.0, fabs(P1))) || !(f1 == f1)) break;
+                    const double d = f1 - f0;
+                    if (d == 0.0) break;
+                    const double Pn = P1 - f1 * (P1 - P0) / d;
+                    P0 = P1; f0 = f1; P1 = Pn;
+                    rows(q, P1, r1, r2);
+                    f1 = r1 - p + P1;
+                }
+                if ((f1 == f1) && fabs(f1) <= 1e-8 * fmax(1.0, fabs(p))) {
+                    Praw = P1;
+                    have_r2 = true;                              // r2 belongs to (q, P1)
+                }
             }
-            if ((f1 == f1) && fabs(f1) <= 1e-8 * fmax(1.0, fabs(p))) {
-                pn = P1;
-                qn = r2 + q;                                 // Eq. (43): Delta q from the same evaluation
-                if (a.wrap) qn -= 6.283185307179586477 * floor(qn / 6.283185307179586477);
+            if (Praw == Praw) {
+                pdn = pd + (Praw - p);                           // unwrapped momentum (04_standard_map/func.py:234)
+                pn = Praw;
+                if (a.mode & SGPR_MAP_WRAP_P) pn -= twopi * floor(pn / twopi);
+                if (!have_r2 || pn != Praw) rows(q, pn, r1, r2);
+                qn = r2 + q;                                     // Eq. (43)
+                if (a.mode & SGPR_MAP_WRAP_Q) qn -= twopi * floor(qn / twopi);
             }
         }
-        q = qn; p = pn;
+        q = qn; p = pn; pd = pdn;
         if (threadIdx.x == 0) {
             a.qmap[(size_t)(i + 1) * a.ntest + k] = q;
             a.pmap[(size_t)(i + 1) * a.ntest + k] = p;
+            if (a.pdiff) a.pdiff[(size_t)(i + 1) * a.ntest + k] = pd;
         }
     }
 }
@@ -605,11 +628,19 @@ int kernel_eval(int family, int which, int m, const double *xa, const double *ya
                 const double *yb, const KConst &kc, double *out, hipStream_t st)
 {
     if (m <= 0) return 0;
-    if (which < 0 || which > 3) { set_error("unknown kernel function"); return SGPR_E_ARG; }
+    const int deriv = which >> 2;
+    which &= 3;
+    if (deriv < 0 || deriv > 2) { set_error("unknown kernel function"); return SGPR_E_ARG; }
+    if (deriv != DERIV_NONE && family == SGPR_FAM_B) {
+        set_error("length-scale derivatives are not available for the sum kernel (family B)");
+        return SGPR_E_ARG;
+    }
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
-        hipLaunchKernelGGL((kernel_eval_kernel<F>), dim3((m + 255) / 256), dim3(256), 0, st, which,
-                           m, xa, ya, xb, yb, kc, out);
+        const dim3 grid((m + 255) / 256);
+        if (deriv == DERIV_LX)      hipLaunchKernelGGL((kernel_eval_kernel<F, DERIV_LX>), grid, dim3(256), 0, st, which, m, xa, ya, xb, yb, kc, out);
+        else if (deriv == DERIV_LY) hipLaunchKernelGGL((kernel_eval_kernel<F, DERIV_LY>), grid, dim3(256), 0, st, which, m, xa, ya, xb, yb, kc, out);
+        else                        hipLaunchKernelGGL((kernel_eval_kernel<F, DERIV_NONE>), grid, dim3(256), 0, st, which, m, xa, ya, xb, yb, kc, out);
         SGPR_CHECK_LAUNCH();
         return 0;
     });
@@ -629,13 +660,13 @@ int predict_rows(int family, int m, const double *q, const double *P, int n0, co
     });
 }
 
-int applymap(int family, int wrap, int nm, int ntest, int n0, const double *xtr, const double *ytr,
+int applymap(int family, int mode, int nm, int ntest, int n0, const double *xtr, const double *ytr,
              const KConst &kc, const double *alpha, int n0p, const double *xtrp, const double *ytrp,
              const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
-             double *pmap, hipStream_t st)
+             double *pmap, double *pdiff, hipStream_t st)
 {
     if (nm <= 0 || ntest <= 0) return 0;
-    MapArgs a{nm, ntest, n0, n0p, wrap, 60, 1e-13, xtr, ytr, alpha, xtrp, ytrp, alphap, Q0, P0, qmap, pmap, kc, kcp};
+    MapArgs a{nm, ntest, n0, n0p, mode, 60, 1e-13, xtr, ytr, alpha, xtrp, ytrp, alphap, Q0, P0, qmap, pmap, pdiff, kc, kcp};
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
         hipLaunchKernelGGL((applymap_kernel<F>), dim3(ntest), dim3(GT), 0, st, a);

@@ -11,19 +11,24 @@ from . import _lib as L
 
 
 class SympFit:
-    def __init__(self, family, x, y, z, hyp, sig2n, lower_only=True, stream=None, reg=False):
-        """reg=True: the scalar-kernel GP of buildKreg / nll_chol_reg (order n = len(x))."""
+    def __init__(self, family, x, y, z, hyp, sig2n, lower_only=True, stream=None, reg=False, block=None):
+        """reg=True: the scalar-kernel GP of buildKreg / nll_chol_reg (order n = len(x)).
+        block="qq" | "PP": only that diagonal block of build_K (order n = len(x)), the systems
+        nll_expl factors (04_standard_map/func.py:126-141)."""
         self._lib = L.load_library()
         self._h = C.c_void_p()
         x, y, hyp = L.f64(x), L.f64(y), L.f64(hyp)
         if x.shape != y.shape or x.ndim != 1:
             raise ValueError("x and y must be 1-D arrays of equal length")
         self.n_pts = len(x)
-        self.n = self.n_pts if reg else 2 * self.n_pts
+        if block not in (None, "qq", "PP") or (block and reg):
+            raise ValueError("block must be None, 'qq' or 'PP' (and excludes reg)")
+        self.n = self.n_pts if (reg or block) else 2 * self.n_pts
         z = L.f64(z) if z is not None else np.zeros(self.n)
         if z.shape != (self.n,):
             raise ValueError("z must have length %d" % self.n)
         flags = (L.FIT_LOWER_ONLY if lower_only else 0) | (L.FIT_REG if reg else 0)
+        flags |= {None: 0, "qq": L.FIT_BLOCK_QQ, "PP": L.FIT_BLOCK_PP}[block]
         L.check(self._lib.sgpr_fit_create(L.family_id(family), self.n_pts, L.dptr(x), L.dptr(y), L.dptr(z),
                                           L.dptr(hyp), len(hyp), float(sig2n), flags,
                                           C.c_void_p(stream or 0), C.byref(self._h)), "sgpr_fit_create")
@@ -110,6 +115,25 @@ class SympFit:
         g = np.empty(2)
         L.check(self._lib.sgpr_fit_nll_grad(self._h, L.dptr(g)), "sgpr_fit_nll_grad")
         return g
+
+    def nll_grad_terms(self):
+        """[alpha^T dK_lx alpha, tr(Ky^-1 dK_lx), alpha^T dK_ly alpha, tr(Ky^-1 dK_ly), tr(Ky^-1)]: the
+        pieces of Rasmussen (5.9) the per-example nll_grad variants recombine."""
+        t = np.empty(5)
+        L.check(self._lib.sgpr_fit_nll_grad_terms(self._h, L.dptr(t)), "sgpr_fit_nll_grad_terms")
+        return t
+
+    def eig(self):
+        """-> (w, c): eigenvalues of Ky = K + |sig2n| I (ascending) and c = Q^T z, computed on the
+        device (parallel Jacobi).  The failure path of the drivers' nll_chol: their
+        `except: eigsh(Ky, neig, ...)` branch (02_pert_pendulum/func.py:194-203).  The handle has to
+        be run() again before other queries."""
+        w, c = np.empty(self.n), np.empty(self.n)
+        rc = self._lib.sgpr_fit_eig(self._h, L.dptr(w), L.dptr(c))
+        if rc > 0:
+            raise np.linalg.LinAlgError("Jacobi eigen-solver did not converge")
+        L.check(rc, "sgpr_fit_eig")
+        return w, c
 
     def inverse(self):
         """Ky^-1 as an F-ordered host array (the drivers' scipy.linalg.inv(K + sig2n I))."""

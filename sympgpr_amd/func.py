@@ -127,23 +127,9 @@ def _applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain
     """The recurrences of the reference's double loop (functions/func.py:216-237) with all nm steps
     of all Ntest orbits inside one device launch (sgpr_applymap_host): alpha = Kyinv ztrain is
     formed once instead of inside every calcP / calcQ call."""
-    from . import _lib as L
-    lib = L.load_library()
-    Ntrain, Ntrainp = len(xtrain) // 2, len(xtrainp) // 2
-    f = L.f64
-    xt, yt = f(xtrain[:Ntrain]), f(xtrain[Ntrain:2 * Ntrain])
-    xp, yp = f(xtrainp[:Ntrainp]), f(xtrainp[Ntrainp:2 * Ntrainp])
-    alpha = f(np.asarray(Kyinv, dtype=np.float64) @ np.asarray(ztrain, dtype=np.float64))
-    alphap = f(np.asarray(Kyinvp, dtype=np.float64) @ np.asarray(ztrainp, dtype=np.float64))
-    hyp, hypp = f(l), f(hypp)
-    Q0, P0 = f(np.broadcast_to(Q0map, (Ntest,))), f(np.broadcast_to(P0map, (Ntest,)))
-    pmap = np.zeros([nm, Ntest])
-    qmap = np.zeros([nm, Ntest])
-    L.check(lib.sgpr_applymap_host(L.family_id(get_family()), int(bool(wrap)), nm, Ntest, L.dptr(hyp), len(hyp),
-                                   Ntrain, L.dptr(xt), L.dptr(yt), L.dptr(alpha), L.dptr(hypp), len(hypp), Ntrainp,
-                                   L.dptr(xp), L.dptr(yp), L.dptr(alphap), L.dptr(Q0), L.dptr(P0), L.dptr(qmap),
-                                   L.dptr(pmap)), "sgpr_applymap_host")
-    return qmap, pmap
+    from .maps import WRAP_Q, run_map
+    return run_map(WRAP_Q if wrap else 0, nm, Ntest, l, Q0map, P0map, xtrain, ztrain, Kyinv, hypp, xtrainp,
+                   ztrainp, Kyinvp)
 
 
 def applymap(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, xtrain, ztrain, Kyinv):

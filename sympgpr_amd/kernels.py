@@ -3,13 +3,15 @@ functions that enter the Gram matrix, `name_num(x_a, y_a, x_b, y_b, lx, ly[, p])
 the same device code the Gram kernels use (sgpr_kernel_eval_host).  Arguments may be scalars
 (-> float, like f2py) or broadcastable arrays (-> array, one batched launch).
 
-The 15 remaining functions of a kernels*.f90 (first / third derivatives, length-scale
-derivatives; kernels.f90:12-57,95-231) are only used by build_dK / nll_grad and are not mirrored
-yet."""
+The eight length-scale derivatives build_dK / build_dKreg call (kernels.f90:133-231) are here
+as well (product kernels A, C, D).  The seven functions no caller in the reference uses (dkdx,
+dkdy, dkdx0, dkdy0 and the three d3k...dy0 functions, kernels.f90:12-57,95-132) are not mirrored."""
 from . import _lib as L
 from . import ops
 
-__all__ = ["kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num"]
+__all__ = ["kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num", "dkdlx_num", "dkdly_num",
+           "d3kdxdx0dlx_num", "d3kdydy0dlx_num", "d3kdxdy0dlx_num", "d3kdxdx0dly_num", "d3kdydy0dly_num",
+           "d3kdxdy0dly_num"]
 
 
 def _eval(which, x_a, y_a, x_b, y_b, lx, ly, p):
@@ -39,3 +41,35 @@ def d2kdydy0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):      # kernels.f90:71-82
 
 def d2kdxdy0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):      # kernels.f90:83-94
     return _eval(L.K_DXDY0, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def dkdlx_num(x_a, y_a, x_b, y_b, lx, ly, p=None):         # kernels.f90:133-143
+    return _eval(L.K_KERN | L.K_DLX, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def dkdly_num(x_a, y_a, x_b, y_b, lx, ly, p=None):         # kernels.f90:144-154
+    return _eval(L.K_KERN | L.K_DLY, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdxdx0dlx_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:155-168
+    return _eval(L.K_DXDX0 | L.K_DLX, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdydy0dlx_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:169-180
+    return _eval(L.K_DYDY0 | L.K_DLX, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdxdy0dlx_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:181-193
+    return _eval(L.K_DXDY0 | L.K_DLX, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdxdx0dly_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:194-206
+    return _eval(L.K_DXDX0 | L.K_DLY, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdydy0dly_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:207-218
+    return _eval(L.K_DYDY0 | L.K_DLY, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdxdy0dly_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:219-231
+    return _eval(L.K_DXDY0 | L.K_DLY, x_a, y_a, x_b, y_b, lx, ly, p)

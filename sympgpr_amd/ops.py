@@ -1,5 +1,7 @@
 """Host-array front-ends of the C ABI (NumPy in, NumPy out).  Each call stages through HBM;
 large problems should use ``fit.SympFit`` which keeps K on the device."""
+import contextlib
+
 import numpy as np
 
 from . import _lib as L
@@ -19,6 +21,18 @@ def set_family(fam):
 
 def get_family():
     return _FAMILY
+
+
+@contextlib.contextmanager
+def family_scope(fam):
+    """Temporarily select a kernel family (the per-example modules under sympgpr_amd/examples
+    each correspond to one kernels*.f90 of the reference)."""
+    old = _FAMILY
+    set_family(fam)
+    try:
+        yield
+    finally:
+        set_family(old)
 
 
 def _check_inout(K, shape):
@@ -84,6 +98,22 @@ def cholesky(Ky, lower=True):
         raise ValueError("expected square matrix")
     L.check(lib.sgpr_potrf_host(A.shape[0], L.dptr(A), max(A.shape[0], 1)), "sgpr_potrf_host")
     return A
+
+
+def eigh(A):
+    """Dense symmetric eigen-decomposition on the device -> (w ascending, Q): what the drivers'
+    `eigsh(Ky, neig, ...)` fallback reduces to (python/02_pert_pendulum/func.py:199); the lower
+    triangle of A is read."""
+    lib = L.load_library()
+    Q = np.array(A, dtype=np.float64, order="F")
+    if Q.ndim != 2 or Q.shape[0] != Q.shape[1]:
+        raise ValueError("expected square matrix")
+    w = np.empty(Q.shape[0])
+    rc = lib.sgpr_syev_host(Q.shape[0], L.dptr(Q), max(Q.shape[0], 1), L.dptr(w))
+    if rc > 0:
+        raise np.linalg.LinAlgError("Jacobi eigen-solver did not converge")
+    L.check(rc, "sgpr_syev_host")
+    return w, Q
 
 
 def solve_cholesky(Lfac, b):

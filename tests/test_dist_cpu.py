@@ -133,3 +133,45 @@ def test_block_cyclic_not_pd_reports_same_info_everywhere():
 def test_grid_shape():
     from sympgpr_amd.dist import grid_shape
     assert [grid_shape(w) for w in (1, 2, 4, 6, 8)] == [(1, 1), (2, 1), (2, 2), (3, 2), (4, 2)]
+
+
+def _oracle_fit(family, x, y, z, hyp, sig2n, reg):
+    from oracle.oracle import Oracle
+    a, nll, _ = Oracle().fit(family, x, y, z, hyp, sig2n)
+    return a, nll
+
+
+def _worker_sections(rank, world, port, nph, Np, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SYMPGPR_NO_TORCH_PRELOAD"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympgpr_amd import sections
+        rng = np.random.default_rng(13)
+        xtrain = np.vstack((rng.uniform(0, 2 * np.pi, (Np, nph)), rng.uniform(-3, 3, (Np, nph))))
+        ztrain = rng.standard_normal((2 * Np, nph))
+        hyp = np.column_stack((rng.uniform(0.4, 0.7, nph), rng.uniform(0.6, 0.9, nph), np.ones(nph)))
+        loc = sections.fit_sections("A", xtrain, ztrain, hyp, 1e-3, rank=rank, world=world, fit_fn=_oracle_fit)
+        assert sorted(loc) == sections.owned_sections(nph, rank, world)
+        alphas, nlls = sections.gather_sections(loc, nph)
+        out[rank] = (np.array(alphas), np.array(nlls), xtrain, ztrain, hyp)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nph", [(2, 5), (3, 2)])
+def test_sections_are_replicas_only(oracle, world, nph):
+    """Split_SympGPR's nphmap independent fits: section m on rank m % world, no data-path
+    collective, every rank ends up with every section's weights (also with idle ranks)."""
+    Np = 24
+    out = mp.Manager().dict()
+    mp.spawn(_worker_sections, args=(world, _free_port(), nph, Np, out), nprocs=world, join=True)
+    a0, n0, xtrain, ztrain, hyp = out[0]
+    for r in range(1, world):
+        assert np.array_equal(out[r][0], a0) and np.array_equal(out[r][1], n0)
+    for m in range(nph):
+        a, nll, _ = oracle.fit("A", xtrain[:Np, m], xtrain[Np:, m], ztrain[:, m], hyp[m], 1e-3)
+        assert np.array_equal(a0[m], a) and n0[m] == nll

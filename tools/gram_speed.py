@@ -1,0 +1,29 @@
+"""Gram-build time: the one-pair kernel (gram_pairs) vs the general-d kernel run at d = 1.
+python tools/gram_speed.py [N]"""
+import ctypes as C
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, "."); sys.path.insert(0, "..")
+from sympgpr_amd import _lib as L
+from sympgpr_amd.dist import HipOps
+from bench import synth
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+q, P, z, hyp, s2 = synth(N)
+n = 2 * N
+ops = HipOps(torch.device("cuda", 0))
+A = ops.empty(n * n)
+dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+x, y = dev(q), dev(P)
+X = dev(np.concatenate([q, P]))
+def timeit(fn):
+    ts = []
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return ts
+t1 = timeit(lambda: ops.gram_pairs("A", N, N, x, y, x, y, hyp, A, [0, N, N * n, N + N * n], n, L.G_ALL))
+t2 = timeit(lambda: ops.gram_nd("A", 1, N, N, X, X, hyp, A, n))
+for name, ts in (("gram_pairs", t1), ("gram_nd d=1", t2)):
+    print("%-12s %s ms -> %.0f GB/s" % (name, ["%.2f" % t for t in ts], 8.0 * n * n / min(ts) / 1e6))
