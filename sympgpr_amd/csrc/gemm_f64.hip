@@ -71,7 +71,8 @@ struct GemmArgs {
 // `tri`: square SYRK with the diagonal at 0 -- only super-tiles touching the lower triangle are
 // enumerated (column-major over super-columns), so no workgroup slot is spent on an early exit.
 // The super-tile is SR x SC tiles with SR*BM == 4*SC*BN (2048 x 512 of C for the 256x128 shape,
-// 1024 x 256 for the 128x128 shape), which is what the triangular closed form assumes.
+// 1024 x 256 for the 128x128 shape), which is what the triangular closed form assumes; any square
+// size works (checked exhaustively on the host against the set of needed tiles).
 constexpr int SR = 8;
 template <int SC>
 __device__ __forceinline__ bool tile_of(const GemmArgs &g, int &tile_r, int &tile_c)
@@ -85,6 +86,10 @@ __device__ __forceinline__ bool tile_of(const GemmArgs &g, int &tile_r, int &til
     if (!g.tri) {
         sc = S / g.n_sr;
         sr = S - sc * g.n_sr;
+        // lower mode without the closed form (block-cyclic test, diag_off != 0): skew the rows by the
+        // column so that one XCD (S % 8) is not handed the same super-row -- the empty top or the
+        // full bottom of the triangle -- in every super-column
+        if (g.lower) sr = (sr + sc) % g.n_sr;
     } else {
         // super-column sc needs super-rows >= sc / R, R = (SR*BM)/(SC*BN) = 4 super-columns per
         // super-row; columns 4a..4a+3 hold (n_sr - a) super-tiles each.
@@ -611,9 +616,10 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
         if (g.tri) {
             long cnt = 0;
             for (int sc = 0; sc < g.n_sc; ++sc) cnt += g.n_sr - (sc / 4 < g.n_sr ? sc / 4 : g.n_sr);
-            // the closed form in tile_of assumes every super-column 4a..4a+3 exists
-            if (g.n_sc != 4 * g.n_sr) g.tri = 0;
-            else g.n_super = (int)cnt;
+            // groups of 4 super-columns share a first needed super-row; the last group may be
+            // partial (n_sc <= 4 n_sr always holds for m == n), which the closed form in tile_of
+            // tolerates because S < n_super never reaches a missing column
+            g.n_super = (int)cnt;
         }
         if (!g.tri) g.n_super = g.n_sr * g.n_sc;
         return (unsigned)(((g.n_super + 7) / 8) * 8 * SR * SC);

@@ -140,7 +140,10 @@ def _dev(a):
 
 
 @pytest.mark.parametrize("shape", [(256, 128, 64), (300, 200, 37), (128, 128, 128), (1000, 1000, 500),
-                                   (64, 17, 3), (2048, 2048, 256)])
+                                   (64, 17, 3), (2048, 2048, 256),
+                                   # squares whose tile counts are not multiples of the super-tile:
+                                   # the triangular enumeration with a partial last column group
+                                   (1536, 1536, 48), (2560, 2560, 32), (5000, 5000, 16), (6656, 6656, 16)])
 @pytest.mark.parametrize("lower", [0, 1])
 def test_gemm_nt(shape, lower):
     """C = beta C + alpha A B^T with asymmetric random operands (catches a transposed
