@@ -341,7 +341,11 @@ struct Ctx {
     double *inv;   // leaf inverses: leaf t at inv + t * LEAF * LEAF
     int *dinfo;
     hipStream_t st;
+    int la_max = 0;   // potrf_rec hands blocks of order <= la_max to the look-ahead driver (0: never)
 };
+
+int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0);
+inline int la_block(int n) { return n <= 8192 ? 256 : (n <= 24576 ? 512 : 1024); }
 
 int trsm_rec(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, int off, const Ctx &c)
 {
@@ -383,6 +387,9 @@ int potrf_rec(int n, double *A, size_t lda, int off, const Ctx &c)
         SGPR_CHECK_LAUNCH();
         return 0;
     }
+    // mid-size blocks (also the halves a large recursive factorisation splits into): blocked
+    // right-looking with the next panel on a side stream
+    if (n > 4 * LEAF && n <= c.la_max) return potrf_lookahead(n, A, lda, c, la_block(n), off);
     const int n1 = split(n), n2 = n - n1;
     double *A21 = A + n1, *A22 = A + n1 + (size_t)n1 * lda;
     int rc = potrf_rec(n1, A, lda, off, c);
@@ -443,9 +450,12 @@ inline size_t inv_bytes(int n)
     return (size_t)((n + LEAF - 1) / LEAF) * LEAF * LEAF * sizeof(double);
 }
 
+
 }  // namespace
 
 size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + 256; }
+
+namespace {
 
 // Right-looking blocked factorisation with one panel of look-ahead on a side stream -- the form
 // used below ~50k, where the recursion's serial chain of leaves and small panel solves would leave
@@ -461,7 +471,7 @@ size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + 256; }
 // loses 6 % of the chip and the tile map its 256-CU geometry).
 // The numbers are the same operations in a different order; the leaf workspace layout is shared with
 // the recursive driver, so the solves do not care which one produced L.
-static int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb)
+int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0)
 {
     static hipStream_t side[64] = {};          // one side stream per device, created on first use
     int dev = 0;
@@ -481,13 +491,13 @@ static int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb)
         return rc;
     };
     const hipStream_t su = c.st;
-    Ctx cp{c.inv, c.dinfo, sp};
+    Ctx cp{c.inv, c.dinfo, sp, 0};
     auto panel = [&](int k) -> int {   // on the P stream
         const int k0 = k * nb, w = std::min(nb, n - k0), below = n - k0 - w;
         double *Akk = A + k0 + (size_t)k0 * lda;
-        int rc = potrf_rec(w, Akk, lda, k0, cp);
+        int rc = potrf_rec(w, Akk, lda, off0 + k0, cp);
         if (rc) return rc;
-        if (below > 0) rc = trsm_rec(below, w, Akk, lda, Akk + w, lda, k0, cp);
+        if (below > 0) rc = trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
         return rc;
     };
     int rc;
@@ -519,20 +529,22 @@ static int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb)
     return cleanup(0);
 }
 
+}  // namespace
+
 int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st)
 {
     if (n < 0 || (n > 0 && lda < (size_t)n)) { set_error("potrf: bad n / lda"); return SGPR_E_ARG; }
     if (lwork < potrf_workspace(n)) { set_error("potrf: workspace too small"); return SGPR_E_ARG; }
     SGPR_HIP(hipMemsetAsync(dinfo, 0, sizeof(int), st));
     if (n == 0) return 0;
-    Ctx c{static_cast<double *>(work), dinfo, st};
-    // blocked + look-ahead for mid sizes, recursive above (measured crossover; SGPR_POTRF=rec|la overrides)
+    // blocked + look-ahead for mid sizes and for the mid-size blocks of a large recursive
+    // factorisation, recursive above (measured crossover; SGPR_POTRF=rec|la overrides)
     static const int mode = [] { const char *e = getenv("SGPR_POTRF"); return !e ? 0 : (e[0] == 'r' ? 1 : 2); }();
     static const int nb_env = [] { const char *e = getenv("SGPR_POTRF_NB"); return e ? atoi(e) : 0; }();
-    const bool la = mode == 2 || (mode == 0 && n > 4 * LEAF && n <= 57344);
-    if (!la) return potrf_rec(n, A, lda, 0, c);
-    const int nb = nb_env > 0 ? nb_env : (n <= 8192 ? 256 : (n <= 24576 ? 512 : 1024));
-    return potrf_lookahead(n, A, lda, c, nb);
+    Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : 57344};
+    if (mode == 2 || (nb_env > 0 && mode == 0 && n > 4 * LEAF && n <= c.la_max))
+        return potrf_lookahead(n, A, lda, c, nb_env > 0 ? nb_env : la_block(n), 0);
+    return potrf_rec(n, A, lda, 0, c);
 }
 
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
