@@ -37,6 +37,12 @@ unsigned long long *g_stamps = nullptr;  // set by gemm_set_stamps (diagnostics 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// LDS stages of the 256x128 LDS-DMA body.  3 (156 KiB, tile t+2 in flight) was measured against 2 on
+// one box: 8192^3 probe 73.2 vs 73.4 TFLOP/s, n = 131072 factorisation 11.17 vs 11.02 s -- the
+// pipeline is not waiting for memory, so the deeper prefetch only adds outstanding traffic.
+#ifndef SGPR_GEMM_STAGES
+#define SGPR_GEMM_STAGES 2
+#endif
 constexpr int BK = 16;
 constexpr int PAD = 16;
 
@@ -382,7 +388,7 @@ __device__ __forceinline__ void read_frags(unsigned aA, unsigned aB, double (&fa
 }
 #define SGPR_LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-template <int BM, int BN>
+template <int BM, int BN, int STAGES>
 __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, int tile_r, int tile_c)
 {
     constexpr int WGM = BM / 64, WGN = BN / 64;
@@ -390,8 +396,9 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
     constexpr int QA = BK * (BM / 128) / NW, QB = BK * (BN / 128) / NW;  // DMA instructions per wave
     static_assert(QA >= 1 && QB >= 1 && BM % 128 == 0 && BN % 128 == 0, "tile / wave count mismatch");
+    static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
     double *const sA0 = smem;
-    double *const sB0 = smem + 2 * BK * LDA_S;
+    double *const sB0 = smem + STAGES * BK * LDA_S;
     const int row0 = tile_r * BM, col0 = tile_c * BN;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -454,30 +461,41 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
     const unsigned baseA = lds_addr(sA0 + wm * 64 + l15 + l4 * LDA_S);
     const unsigned baseB = lds_addr(sB0 + wn * 64 + l15 + l4 * LDB_S);
 
+    // AHEAD = how many tiles beyond the current one are in flight or landed: 1 (two stages) or 2.
+    constexpr int AHEAD = STAGES - 1;
     if (T > 0) {
         dma(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAGES == 3 && T > 1) {
+            dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");   // tile 0 landed, tile 1 in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         read_frags<0, LDA_S, LDB_S>(baseA, baseB, fa0, fb0);
     }
-    // One k-step.  MORE (compile time): tile t+1 exists -- the steady-state body has no branch at
-    // all: a single scalar branch in this instruction stream costs ~50 cycles of MFMA issue per use
-    // (measured: seven `if (more)` tests per step = 350 of 8700 cycles), so the last step is peeled.
-    auto kstep = [&](int t, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        const int cur = t & 1;
+    // One k-step.  ISSUE (compile time): tile t+AHEAD exists and is requested in this step; NEXT:
+    // tile t+1 exists.  The steady-state body has no branch at all: a single scalar branch in this
+    // instruction stream costs ~50 cycles of MFMA issue per use (measured: seven `if (more)` tests
+    // per step = 350 of 8700 cycles), so the last step(s) are peeled.
+    // Buffers: tile t lives in buffer t % STAGES.  The copy of tile t+AHEAD targets the buffer tile
+    // t-1 occupied, which every wave released at the barrier of step t-1.
+    auto kstep = [&](int t, int cur, auto issue_tag, auto next_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value, NEXT = decltype(next_tag)::value;
+        const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+        const int tgt = (STAGES == 2) ? nxt : ((nxt + 1 == STAGES) ? 0 : nxt + 1);
         const unsigned aA = baseA + cur * (BK * LDA_S * 8), aB = baseB + cur * (BK * LDB_S * 8);
         __builtin_amdgcn_sched_barrier(0);
-        // kk = 0 and 1: the copy of tile t+1 goes out one LDS-DMA instruction per MFMA row, so the
+        // kk = 0 and 1: the copy of tile t+AHEAD goes out one LDS-DMA instruction per MFMA row, so the
         // matrix pipe never waits behind a burst of address arithmetic + DMA issue
         read_frags<1, LDA_S, LDB_S>(aA, aB, fa1, fb1);
         SGPR_LGKM_WAIT(8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mfma_rows(fa0, fb0, i, i + 1);
-            if constexpr (MORE) {
+            if constexpr (ISSUE) {
 #pragma unroll
-                for (int q = i * NQ / 8; q < (i + 1) * NQ / 8; ++q) dma_one(t + 1, cur ^ 1, q);
+                for (int q = i * NQ / 8; q < (i + 1) * NQ / 8; ++q) dma_one(t + AHEAD, tgt, q);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -486,9 +504,9 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             mfma_rows(fa1, fb1, i, i + 1);
-            if constexpr (MORE) {
+            if constexpr (ISSUE) {
 #pragma unroll
-                for (int q = (4 + i) * NQ / 8; q < (5 + i) * NQ / 8; ++q) dma_one(t + 1, cur ^ 1, q);
+                for (int q = (4 + i) * NQ / 8; q < (5 + i) * NQ / 8; ++q) dma_one(t + AHEAD, tgt, q);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -501,19 +519,27 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
         SGPR_LGKM_WAIT(0);
         mfma_rows(fa1, fb1, 0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MORE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile t+1 has landed
+        if constexpr (NEXT) {
+            // this wave's share of tile t+1 has landed (with three stages the copies of tile t+2
+            // issued above may still be in flight)
+            if constexpr (STAGES == 3 && ISSUE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+            else                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned nA = baseA + (cur ^ 1) * (BK * LDA_S * 8), nB = baseB + (cur ^ 1) * (BK * LDB_S * 8);
+            const unsigned nA = baseA + nxt * (BK * LDA_S * 8), nB = baseB + nxt * (BK * LDB_S * 8);
             read_frags<0, LDA_S, LDB_S>(nA, nB, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
         }
         mfma_rows(fa1, fb1, 2, 4);
         __builtin_amdgcn_sched_barrier(0);
+        return nxt;
     };
-    for (int t = 0; t + 1 < T; ++t) kstep(t, std::true_type());
-    if (T > 0) kstep(T - 1, std::false_type());
+    {
+        int t = 0, cur = 0;
+        for (; t + AHEAD < T; ++t) cur = kstep(t, cur, std::true_type(), std::true_type());
+        for (; t + 1 < T; ++t) cur = kstep(t, cur, std::false_type(), std::true_type());
+        if (t < T) kstep(t, cur, std::false_type(), std::false_type());
+    }
     SGPR_LGKM_WAIT(0);
 
     if (g.stamps && tid == 0) {
@@ -547,7 +573,9 @@ template <int BM, int BN>
 __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (BM >= 128 ? 2 : 1)) void gemm_nt_kernel(const GemmArgs g)
 {
     constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
-    __shared__ double smem[2 * BK * (LDA_S + LDB_S)];
+    // SGPR_GEMM_STAGES for the one-workgroup-per-CU shape (3 = 156 KiB of the CU's 160), two otherwise
+    constexpr int STAGES = (BM == 256 && BN == 128) ? SGPR_GEMM_STAGES : 2;
+    __shared__ double smem[STAGES * BK * (LDA_S + LDB_S)];
     int tile_r, tile_c;
     if (!tile_of<(SR * BM) / (4 * BN)>(g, tile_r, tile_c)) return;
     const int row0 = tile_r * BM, col0 = tile_c * BN;
@@ -563,7 +591,7 @@ __global__ __launch_bounds__(64 * (BM / 64) * (BN / 64), (BM >= 128 ? 2 : 1)) vo
         return;
     }
     if constexpr (BM % 128 == 0) {
-        if (fast && !(g.dbg & 16)) { gemm_body_dma<BM, BN>(g, smem, tile_r, tile_c); return; }
+        if (fast && !(g.dbg & 16)) { gemm_body_dma<BM, BN, STAGES>(g, smem, tile_r, tile_c); return; }
     }
     if (fast) gemm_body<BM, BN, true>(g, smem, tile_r, tile_c);
     else      gemm_body<BM, BN, false>(g, smem, tile_r, tile_c);
