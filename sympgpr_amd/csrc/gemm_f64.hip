@@ -61,6 +61,7 @@ struct GemmArgs {
     unsigned long long *stamps;  // diagnostic: per-workgroup shader-clock / real-time stamps, or null
     // tile -> workgroup map (see tile_of): super-tiles of SR x SC tiles, one per XCD at a time
     int tiles_m, tiles_n, n_sr, n_sc, n_super, tri;
+    int n_full, n_grp;           // tri: full super-tiles (enumerated first), groups of 4 diagonal ones
     // lower-mode skip test in block-cyclic form: a tile is needed iff
     //   (last_row / lblk) * lpr + lpi >= (first_col / lblk) * lpc + lpj
     // single GPU: lblk = 1, lpr = lpc = 1, lpi = diag_off, lpj = 0  (row + diag_off >= col)
@@ -96,20 +97,31 @@ __device__ __forceinline__ bool tile_of(const GemmArgs &g, int &tile_r, int &til
         // column so that one XCD (S % 8) is not handed the same super-row -- the empty top or the
         // full bottom of the triangle -- in every super-column
         if (g.lower) sr = (sr + sc) % g.n_sr;
-    } else {
-        // super-column sc needs super-rows >= sc / R, R = (SR*BM)/(SC*BN) = 4 super-columns per
-        // super-row; columns 4a..4a+3 hold (n_sr - a) super-tiles each.
-        // cum(a) = 4 (a n_sr - a(a-1)/2); find the largest a with cum(a) <= S.
-        const double nsr = (double)g.n_sr;
+    } else if (S < g.n_full) {
+        // Super-column sc needs super-rows >= a = sc / 4 (4 super-columns per super-row of C).  The
+        // super-tiles strictly below that first row are full; they come first, column-major:
+        // columns 4a..4a+3 hold N1 - a of them each, N1 = n_sr - 1, so
+        // cum(a) = 4 (a N1 - a(a-1)/2); find the largest a with cum(a) <= S.
+        const int N1 = g.n_sr - 1;
+        const double nsr = (double)N1;
         int a = (int)((2.0 * nsr + 1.0 - sqrt((2.0 * nsr + 1.0) * (2.0 * nsr + 1.0) - 2.0 * (double)S)) * 0.5);
         if (a < 0) a = 0;
-        while (a > 0 && 4 * (a * g.n_sr - a * (a - 1) / 2) > S) --a;
-        while (4 * ((a + 1) * g.n_sr - (a + 1) * a / 2) <= S) ++a;
-        const int rem = S - 4 * (a * g.n_sr - a * (a - 1) / 2);
-        const int per = g.n_sr - a;
+        while (a > 0 && 4 * (a * N1 - a * (a - 1) / 2) > S) --a;
+        while (4 * ((a + 1) * N1 - (a + 1) * a / 2) <= S) ++a;
+        const int rem = S - 4 * (a * N1 - a * (a - 1) / 2);
+        const int per = N1 - a;
         const int b = rem / per;
         sc = 4 * a + b;
-        sr = a + (rem - b * per);
+        sr = a + 1 + (rem - b * per);
+    } else {
+        // ... then the partially filled super-tiles on the diagonal, ordered by their position b in
+        // the group of four (equal fill) so that S % 8 deals every XCD the same mix.  With them
+        // interleaved in column order two XCDs got all of them: 1 % (n = 65536) to 4 % (16384)
+        // less work than the others, i.e. the kernel ran that much longer than its average XCD.
+        const int d = S - g.n_full;
+        const int b = d / g.n_grp, a = d - b * g.n_grp;
+        sc = 4 * a + b;
+        sr = a;
     }
     tile_r = sr * SR + (w % SR);
     tile_c = sc * SC + (w / SR);
@@ -633,7 +645,7 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
         return SGPR_E_ARG;
     }
     GemmArgs g{m, n, k, alpha, beta, A, lda, B, ldb, C, ldc, lower, diag_off, transb, g_stamps, 0, 0, 0, 0, 0, 0,
-               bc[0], bc[1], bc[2], bc[3], bc[4], g_dbg};
+               0, 0, bc[0], bc[1], bc[2], bc[3], bc[4], g_dbg};
     auto set_map = [&](int bm, int bn) {
         g.tiles_m = (m + bm - 1) / bm;
         g.tiles_n = (n + bn - 1) / bn;
@@ -642,12 +654,13 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
         g.n_sc = (g.tiles_n + SC - 1) / SC;
         g.tri = (lower && diag_off == 0 && m == n) ? 1 : 0;
         if (g.tri) {
-            long cnt = 0;
-            for (int sc = 0; sc < g.n_sc; ++sc) cnt += g.n_sr - (sc / 4 < g.n_sr ? sc / 4 : g.n_sr);
-            // groups of 4 super-columns share a first needed super-row; the last group may be
-            // partial (n_sc <= 4 n_sr always holds for m == n), which the closed form in tile_of
-            // tolerates because S < n_super never reaches a missing column
-            g.n_super = (int)cnt;
+            // full super-tiles below the first needed row of every super-column, then 4 diagonal
+            // slots per group (slots of a partial last group that do not exist exit at once)
+            long full = 0;
+            for (int sc = 0; sc < g.n_sc; ++sc) full += std::max(g.n_sr - sc / 4 - 1, 0);
+            g.n_full = (int)full;
+            g.n_grp = (g.n_sc + 3) / 4;
+            g.n_super = g.n_full + 4 * g.n_grp;
         }
         if (!g.tri) g.n_super = g.n_sr * g.n_sc;
         return (unsigned)(((g.n_super + 7) / 8) * 8 * SR * SC);

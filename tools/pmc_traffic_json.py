@@ -1,0 +1,49 @@
+"""Build profiles/<round>/pmc_traffic_n<order>.json from the two rocprofv3 --pmc passes and the
+per-launch records of the MFMA kernel:
+
+  python tools/pmc_traffic_json.py FETCH_counter_collection.csv WRITE_counter_collection.csv launches.json N_PTS > out.json
+
+launches.json comes from `python tools/gemm_launches.py N --json launches.json`.
+FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950: calibrated on gemv_n,
+which reads L exactly once and reports half of it)."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+fetch_csv, write_csv, launches_json, n_pts = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+
+
+def sums(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].replace("void ", "").replace("sgpr::(anonymous namespace)::", "").split("(")[0]
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+
+ft, fc = sums(fetch_csv, "FETCH_SIZE")
+wt, wc = sums(write_csv, "WRITE_SIZE")
+la = json.load(open(launches_json))
+n = 2 * n_pts
+out = {"config": {"n_pts": n_pts, "order_n": n, "family": "A", "triangle": "full"},
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) of bench.py --steps 1 "
+                 "--warmup 0 --cpu-sample 0 --no-launch-events; FETCH_SIZE doubled per the gfx950 note, calibrated on "
+                 "gemv_n; traffic = (2 FETCH + WRITE) KiB * 1024 / launches"}
+for key, name in (("gemm_nt_kernel<256, 128>", "gemm_nt_kernel<256, 128>"), ("gram_pairs_kernel<0, false, 0>", "gram_pairs_kernel")):
+    f, w, c = ft.get(key, 0.0), wt.get(key, 0.0), max(fc.get(key, 0), 1)
+    out[name] = {"launches": fc.get(key, 0), "fetch_kb_total": f, "write_kb_total": w,
+                 "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0 / c}
+g = out["gemm_nt_kernel<256, 128>"]
+g["algorithmic_bytes_per_launch"] = la["big_compulsory_bytes"] / max(la["big_launches"], 1)
+g["algorithmic_flop_per_launch"] = la["big_flop"] / max(la["big_launches"], 1)
+g["launches_in_event_run"] = la["big_launches"]
+out["gram_pairs_kernel"]["algorithmic_bytes_per_launch"] = 8.0 * n * n
+gv = "gemv_n_kernel"
+if gv in ft:
+    out["calibration_gemv_n"] = {"fetch_kb_total_reported": ft[gv], "bytes_read_algorithmic": 8.0 * n * n / 2}
+print(json.dumps(out, indent=1))
