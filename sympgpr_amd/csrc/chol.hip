@@ -329,6 +329,100 @@ __global__ __launch_bounds__(MV_T) void leaf_matvec_kernel(int nb, const double 
     }
 }
 
+// b(n) := L^-1 b (trans = 0) or L^-T b (trans = 1) for a diagonal block of up to TRSV_BLOCK rows in
+// ONE single-workgroup launch: the leaf-by-leaf substitution (x_j = inv(L_jj) b_j, off-diagonal
+// leaf rows folded in before it) that the recursion would spread over 2 n/128 - 1 launches.  A
+// triangular solve with one right-hand side is a chain of dependent ~10 us launches otherwise --
+// 510 of them for n = 16384, where the solve stage was a tenth of the whole fit.
+constexpr int TRSV_BLOCK = 512;
+__global__ __launch_bounds__(MV_T) void trsv_block_kernel(int n, const double *L, size_t ldl,
+                                                          const double *inv, double *b, int trans)
+{
+    __shared__ double sx[TRSV_BLOCK];               // b on entry, x as it is produced
+    __shared__ double part[MV_T / LEAF][LEAF];
+    const int t = threadIdx.x, i = t & (LEAF - 1), ks = t >> 7;    // 128 rows x 8 slices
+    const int lane = t & 63, wave = t >> 6;
+    for (int r = t; r < TRSV_BLOCK; r += MV_T) sx[r] = r < n ? b[r] : 0.0;
+    __syncthreads();
+    const int nl = (n + LEAF - 1) / LEAF;
+    for (int jj = 0; jj < nl; ++jj) {
+        const int j = trans ? nl - 1 - jj : jj;
+        const int r0 = j * LEAF, nj = min(LEAF, n - r0);
+        // ---- fold the already known x into b_j
+        if (!trans) {
+            // b_j[i] -= sum_{c < r0} L[r0 + i, c] x[c]: rows contiguous -> thread (i, slice) strides the columns
+            // (r0 is a multiple of 128: 16 columns per slice and leaf, four independent chains)
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            if (i < nj) {
+                const double *row = L + (size_t)(r0 + i);
+                for (int c = ks; c < r0; c += 4 * (MV_T / LEAF)) {
+                    const double l0 = row[(size_t)c * ldl], l1 = row[(size_t)(c + 8) * ldl];
+                    const double l2 = row[(size_t)(c + 16) * ldl], l3 = row[(size_t)(c + 24) * ldl];
+                    a0 = __builtin_fma(l0, sx[c], a0);
+                    a1 = __builtin_fma(l1, sx[c + 8], a1);
+                    a2 = __builtin_fma(l2, sx[c + 16], a2);
+                    a3 = __builtin_fma(l3, sx[c + 24], a3);
+                }
+            }
+            const double acc = (a0 + a1) + (a2 + a3);
+            part[ks][i] = acc;
+            __syncthreads();
+            if (t < nj) {
+                double r = 0.0;
+#pragma unroll
+                for (int q = 0; q < MV_T / LEAF; ++q) r += part[q][t];
+                sx[r0 + t] -= r;
+            }
+        } else {
+            // b_j[c] -= sum_{r >= r0 + LEAF} L[r, r0 + c] x[r]: one wave per column, lanes stride the rows
+            const int rb = r0 + LEAF;
+            constexpr int NWV = MV_T / 64, CPW = LEAF / NWV;   // 16 waves, 8 columns each
+            double acc[CPW];
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) acc[q] = 0.0;
+            const double *col0 = L + (size_t)(r0 + wave) * ldl;
+            for (int r = rb + lane; r < n; r += 64) {          // the 8 columns' loads go out together
+                const double xr = sx[r];
+#pragma unroll
+                for (int q = 0; q < CPW; ++q) {
+                    const int c = wave + q * NWV;
+                    const double v = c < nj ? col0[(size_t)q * NWV * ldl + r] : 0.0;
+                    acc[q] = __builtin_fma(v, xr, acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CPW; ++q) {
+                double a = acc[q];
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+                if (lane == 0) part[0][wave + q * NWV] = a;
+            }
+            __syncthreads();
+            if (t < nj) sx[r0 + t] -= part[0][t];
+        }
+        __syncthreads();
+        // ---- x_j = inv(L_jj) b_j  or  inv(L_jj)^T b_j  (inv is zero above the diagonal and outside nj x nj)
+        const double *iv = inv + (size_t)j * LEAF * LEAF;
+        double acc = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < LEAF / (MV_T / LEAF); ++kk) {
+            const int k = ks * (LEAF / (MV_T / LEAF)) + kk;
+            const double m = trans ? iv[k + i * LEAF] : iv[i + k * LEAF];
+            acc = __builtin_fma(m, sx[r0 + k], acc);
+        }
+        __syncthreads();                            // every thread has read b_j before it is overwritten
+        part[ks][i] = acc;
+        __syncthreads();
+        if (t < nj) {
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < MV_T / LEAF; ++q) r += part[q][t];
+            sx[r0 + t] = r;
+        }
+        __syncthreads();
+    }
+    for (int r = t; r < n; r += MV_T) b[r] = sx[r];
+}
+
 inline int split(int n)
 {
     // first part: a multiple of LEAF close to n/2 (>= LEAF, < n)
@@ -409,6 +503,12 @@ int trsv_n_rec(int n, const double *L, size_t ldl, double *b, int off, const Ctx
         SGPR_CHECK_LAUNCH();
         return 0;
     }
+    if (n <= TRSV_BLOCK) {
+        hipLaunchKernelGGL(trsv_block_kernel, dim3(1), dim3(MV_T), 0, c.st, n, L, ldl,
+                           c.inv + (size_t)(off / LEAF) * LEAF * LEAF, b, 0);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    }
     const int n1 = split(n), n2 = n - n1;
     int rc = trsv_n_rec(n1, L, ldl, b, off, c);
     if (rc) return rc;
@@ -421,6 +521,12 @@ int trsv_t_rec(int n, const double *L, size_t ldl, double *b, int off, const Ctx
 {
     if (n <= LEAF) {
         hipLaunchKernelGGL(leaf_matvec_kernel, dim3(1), dim3(MV_T), 0, c.st, n,
+                           c.inv + (size_t)(off / LEAF) * LEAF * LEAF, b, 1);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    }
+    if (n <= TRSV_BLOCK) {
+        hipLaunchKernelGGL(trsv_block_kernel, dim3(1), dim3(MV_T), 0, c.st, n, L, ldl,
                            c.inv + (size_t)(off / LEAF) * LEAF * LEAF, b, 1);
         SGPR_CHECK_LAUNCH();
         return 0;
