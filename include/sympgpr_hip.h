@@ -59,7 +59,6 @@ enum { SGPR_G_QQ = 1, SGPR_G_PQ = 2, SGPR_G_QP = 4, SGPR_G_PP = 8, SGPR_G_ALL = 
 
 /* fit flags */
 enum { SGPR_FIT_LOWER_ONLY = 1,  /* build only the lower triangle (what the factor reads)   */
-       SGPR_FIT_KEEP_K = 2,      /* keep an untouched copy of Ky next to L (2x memory)       */
        SGPR_FIT_REG = 4,         /* scalar-kernel GP (buildKreg, n = n_pts): nll_chol_reg     */
        SGPR_FIT_BLOCK_QQ = 8,    /* only the qq block of build_K (n = n_pts): nll_expl ind=0,  */
        SGPR_FIT_BLOCK_PP = 16 }; /* only the PP block, ind=1 (04_standard_map/func.py:126-141) */

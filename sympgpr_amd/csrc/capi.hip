@@ -326,7 +326,7 @@ static int fit_create_common(int family, int d, int n_pts, const double *X, size
     int rc = need_device();
     if (rc) return rc;
     if (!out || n_pts <= 0 || (d == 1 ? (!x || !y) : !X)) { set_error("fit_create: bad arguments"); return SGPR_E_ARG; }
-    if (flags & SGPR_FIT_KEEP_K) { set_error("fit_create: SGPR_FIT_KEEP_K not implemented"); return SGPR_E_ARG; }
+    if (flags & ~(unsigned)(SGPR_FIT_LOWER_ONLY | SGPR_FIT_REG | SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP)) { set_error("fit_create: unknown flag"); return SGPR_E_ARG; }
     if (d != 1 && (flags & SGPR_FIT_REG)) { set_error("fit_create: the scalar-kernel GP exists for d = 1 only"); return SGPR_E_ARG; }
     const unsigned single = flags & (SGPR_FIT_REG | SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP);
     if ((single & (single - 1)) || (d != 1 && single)) {
