@@ -45,7 +45,11 @@ enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/ke
 enum { SGPR_K_KERN = 0, SGPR_K_DXDX0 = 1, SGPR_K_DYDY0 = 2, SGPR_K_DXDY0 = 3,
        /* OR-ed in: the derivative of that function with respect to lx / ly (dkdlx_num,
         * d3kdxdx0dlx_num, ... kernels.f90:133-231; product kernels only) */
-       SGPR_K_DLX = 4, SGPR_K_DLY = 8 };
+       SGPR_K_DLX = 4, SGPR_K_DLY = 8,
+       /* the seven generated functions no caller of the reference uses (kernels.f90:12-57,95-132):
+        * dkdx, dkdy, dkdx0, dkdy0, d3kdxdx0dy0, d3kdydy0dy0, d3kdxdy0dy0 */
+       SGPR_K_DX = 16, SGPR_K_DY = 17, SGPR_K_DX0 = 18, SGPR_K_DY0 = 19, SGPR_K_DXDX0DY0 = 20,
+       SGPR_K_DYDY0DY0 = 21, SGPR_K_DXDY0DY0 = 22 };
 
 enum { SGPR_E_ARG = -1, SGPR_E_NODEVICE = -2, SGPR_E_HIP = -3, SGPR_E_NOMEM = -4,
        SGPR_E_STATE = -5 };

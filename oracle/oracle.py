@@ -51,6 +51,8 @@ class Oracle:
             f.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t, C.c_int]
         L.orc_scalar_dl.restype = C.c_double
         L.orc_scalar_dl.argtypes = [C.c_int, C.c_int] + [C.c_double] * 6
+        L.orc_scalar_x.restype = C.c_double
+        L.orc_scalar_x.argtypes = [C.c_int, C.c_int] + [C.c_double] * 7
         for f in (L.orc_build_dk, L.orc_build_dkreg):
             f.restype = C.c_int
             f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, C.c_size_t]
@@ -107,6 +109,10 @@ class Oracle:
         Lf = self.cholesky(K + abs(sig2n) * np.eye(n))
         alpha = self.solve_cholesky(Lf, z)
         return alpha, self.nll(Lf, z, alpha), Lf
+
+    def scalar_x(self, fam, which, xa, ya, xb, yb, lx, ly, p=0.0):
+        """the seven functions of a kernels*.f90 no caller uses (X_NAMES)"""
+        return self.lib.orc_scalar_x(FAMILIES[fam], which, xa, ya, xb, yb, lx, ly, p)
 
     def scalar_dl(self, fam, which, xa, ya, xb, yb, lx, ly):
         return self.lib.orc_scalar_dl(FAMILIES[fam], which, xa, ya, xb, yb, lx, ly)
@@ -205,6 +211,8 @@ class Oracle:
 
 
 _SCALARS = ("kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num")
+X_NAMES = {16: "dkdx_num", 17: "dkdy_num", 18: "dkdx0_num", 19: "dkdy0_num", 20: "d3kdxdx0dy0_num",
+           21: "d3kdydy0dy0_num", 22: "d3kdxdy0dy0_num"}
 DL_NAMES = {4: "dkdlx_num", 5: "dkdly_num", 6: "d3kdxdx0dlx_num", 7: "d3kdydy0dlx_num", 8: "d3kdxdy0dlx_num",
             9: "d3kdxdx0dly_num", 10: "d3kdydy0dly_num", 11: "d3kdxdy0dly_num"}
 
@@ -236,7 +244,10 @@ class Ref:
         """name_num_(x_a,y_a,x_b,y_b,lx,ly[,p]) of the family's generated kernels file."""
         f = getattr(self.ker[fam], name + "_")
         # family B's zero functions are INTEGER*4 (kernels_sum.f90:79,89,110)
-        f.restype = C.c_int if (fam == "B" and name == "d2kdxdy0_num") else C.c_double
+        # family B's identically-zero functions are INTEGER*4 (kernels_sum.f90:79,89,110)
+        int_zero = ("d2kdxdy0_num", "d3kdxdx0dy0_num", "d3kdxdy0dy0_num", "d3kdydy0dlx_num", "d3kdxdy0dlx_num",
+                    "d3kdxdx0dly_num", "d3kdxdy0dly_num")
+        f.restype = C.c_int if (fam == "B" and name in int_zero) else C.c_double
         args = [C.byref(C.c_double(v)) for v in (xa, ya, xb, yb, lx, ly)]
         if fam == "D":
             args.append(C.byref(C.c_double(p)))

@@ -188,6 +188,63 @@ int orc_build_dk(int fam, int which, int n, int n0, const double *x, const doubl
     return 0;
 }
 
+/* The seven generated functions no caller in the reference uses (first derivatives and the
+ * third derivatives with respect to y_b), restated for the completeness of the `kernels` module:
+ *   A: python/05_tokamak/SympGPR/kernels.f90:12-57,95-132
+ *   B: python/01_pendulum/explicit/kernels_sum.f90:12-55,89-131 (its zero functions are INTEGER*4)
+ *   C: python/03_henon_heiles/kernels_sq.f90:11-54,89-123
+ *   D: python/01_pendulum/implicit_period_unknown/kernels.f90 (7-argument variants)
+ * which: 16 dkdx, 17 dkdy, 18 dkdx0, 19 dkdy0, 20 d3kdxdx0dy0, 21 d3kdydy0dy0, 22 d3kdxdy0dy0 */
+enum { X_DKDX = 16, X_DKDY = 17, X_DKDX0 = 18, X_DKDY0 = 19, X_DXDX0DY0 = 20, X_DYDY0DY0 = 21, X_DXDY0DY0 = 22 };
+double orc_scalar_x(int fam, int which, double x_a, double y_a, double x_b, double y_b,
+                    double lx, double ly, double p)
+{
+    const double lx2 = lx * lx, ly2 = ly * ly;
+    const double dy = y_a - y_b;
+    if (fam == FAM_A || fam == FAM_D) {
+        const double h = fam == FAM_A ? 0.5 * x_a - 0.5 * x_b : p * (x_a - x_b);
+        const double hs = fam == FAM_A ? 0.5 : 1.0 * p;      /* dh/dx_a */
+        const double s = sin(h), c = cos(h);
+        const double cd = fam == FAM_A ? cos(1.0 * x_a - 1.0 * x_b) : cos(2.0 * p * (x_a - x_b));
+        const double E = exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(s)) / (lx2 * ly2));
+        switch (which) {
+        case X_DKDX: return -hs * E * s * c / lx2;
+        case X_DKDY: return 1.0 * (-y_a + y_b) * E / ly2;
+        case X_DKDX0: return hs * E * s * c / lx2;
+        case X_DKDY0: return 1.0 * (y_a - y_b) * E / ly2;
+        case X_DXDX0DY0: return hs * hs * dy * (lx2 * cd - sq(s) * sq(c)) * E / (lx2 * lx2 * ly2);
+        case X_DYDY0DY0: return (3.0 * ly2 - sq(dy)) * dy * E / (ly2 * ly2 * ly2);
+        case X_DXDY0DY0: return hs * (1.0 * ly2 - sq(dy)) * E * s * c / (lx2 * ly2 * ly2);
+        }
+    } else if (fam == FAM_B) {
+        const double s = sin(0.5 * x_a - 0.5 * x_b), c = cos(0.5 * x_a - 0.5 * x_b);
+        const double ex = exp(-0.5 * sq(s) / lx2);
+        const double ey = exp((-0.5 * sq(y_a) + 1.0 * y_a * y_b - 0.5 * sq(y_b)) / ly2);
+        switch (which) {
+        case X_DKDX: return -0.5 * ex * s * c / lx2;
+        case X_DKDY: return 1.0 * (-y_a + y_b) * ey / ly2;
+        case X_DKDX0: return 0.5 * ex * s * c / lx2;
+        case X_DKDY0: return 1.0 * (y_a - y_b) * ey / ly2;
+        case X_DXDX0DY0: return 0.0;
+        case X_DYDY0DY0: return (3.0 * ly2 - 1.0 * sq(dy)) * dy * ey / (ly2 * ly2 * ly2);
+        case X_DXDY0DY0: return 0.0;
+        }
+    } else if (fam == FAM_C) {
+        const double dx = x_a - x_b;
+        const double E = exp(-0.5 * (lx2 * sq(dy) + ly2 * sq(dx)) / (lx2 * ly2));
+        switch (which) {
+        case X_DKDX: return 1.0 * (-x_a + x_b) * E / lx2;
+        case X_DKDY: return 1.0 * (-y_a + y_b) * E / ly2;
+        case X_DKDX0: return 1.0 * (x_a - x_b) * E / lx2;
+        case X_DKDY0: return 1.0 * (y_a - y_b) * E / ly2;
+        case X_DXDX0DY0: return (lx2 - 1.0 * sq(dx)) * dy * E / (lx2 * lx2 * ly2);
+        case X_DYDY0DY0: return (3.0 * ly2 - sq(dy)) * dy * E / (ly2 * ly2 * ly2);
+        case X_DXDY0DY0: return (1.0 * ly2 - sq(dy)) * dx * E / (lx2 * ly2 * ly2);
+        }
+    }
+    return NAN;
+}
+
 /* build_dKreg: python/functions/func.py:52-78.  Output (n x n0): Kp[k,lk] = sig dkdl(x0[lk],y0[lk],x[k],y[k]) */
 int orc_build_dkreg(int fam, int which, int n, int n0, const double *x, const double *y, const double *x0,
                     const double *y0, const double *hyp, double *dK, size_t ld)

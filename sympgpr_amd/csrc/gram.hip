@@ -329,6 +329,62 @@ __global__ void kernel_eval_kernel(int which, int m, const double *xa, const dou
     out[i] = r;
 }
 
+// The seven generated functions no caller of the reference uses (first derivatives, third derivatives
+// with respect to y_b: kernels.f90:12-57,95-132 and the sibling files), for the completeness of the
+// `kernels` module.  Not a hot path: plain device-libs sin / cos / exp.
+template <int FAM>
+__device__ double extra_eval(int which, double xa, double ya, double xb, double yb, const KConst &kc)
+{
+    const double lx2 = kc.lx2, ly2 = kc.ly2, dy = ya - yb;
+    if constexpr (FAM == SGPR_FAM_A || FAM == SGPR_FAM_D) {
+        const double h = FAM == SGPR_FAM_A ? 0.5 * xa - 0.5 * xb : kc.p * (xa - xb);
+        const double hs = FAM == SGPR_FAM_A ? 0.5 : kc.p;
+        const double s = sin(h), c = cos(h), cd = cos(2.0 * h);
+        const double E = exp(-0.5 * (lx2 * dy * dy + ly2 * s * s) / (lx2 * ly2));
+        switch (which) {
+        case SGPR_K_DX: return -hs * E * s * c / lx2;
+        case SGPR_K_DY: return -dy * E / ly2;
+        case SGPR_K_DX0: return hs * E * s * c / lx2;
+        case SGPR_K_DY0: return dy * E / ly2;
+        case SGPR_K_DXDX0DY0: return hs * hs * dy * (lx2 * cd - s * s * c * c) * E / (lx2 * lx2 * ly2);
+        case SGPR_K_DYDY0DY0: return (3.0 * ly2 - dy * dy) * dy * E / (ly2 * ly2 * ly2);
+        default: return hs * (ly2 - dy * dy) * E * s * c / (lx2 * ly2 * ly2);   // SGPR_K_DXDY0DY0
+        }
+    } else if constexpr (FAM == SGPR_FAM_B) {
+        const double h = 0.5 * xa - 0.5 * xb, s = sin(h), c = cos(h);
+        const double ex = exp(-0.5 * s * s / lx2);
+        const double ey = exp((-0.5 * ya * ya + ya * yb - 0.5 * yb * yb) / ly2);
+        switch (which) {
+        case SGPR_K_DX: return -0.5 * ex * s * c / lx2;
+        case SGPR_K_DY: return -dy * ey / ly2;
+        case SGPR_K_DX0: return 0.5 * ex * s * c / lx2;
+        case SGPR_K_DY0: return dy * ey / ly2;
+        case SGPR_K_DYDY0DY0: return (3.0 * ly2 - dy * dy) * dy * ey / (ly2 * ly2 * ly2);
+        default: return 0.0;                                                    // the mixed ones vanish
+        }
+    } else {
+        const double dx = xa - xb;
+        const double E = exp(-0.5 * (lx2 * dy * dy + ly2 * dx * dx) / (lx2 * ly2));
+        switch (which) {
+        case SGPR_K_DX: return -dx * E / lx2;
+        case SGPR_K_DY: return -dy * E / ly2;
+        case SGPR_K_DX0: return dx * E / lx2;
+        case SGPR_K_DY0: return dy * E / ly2;
+        case SGPR_K_DXDX0DY0: return (lx2 - dx * dx) * dy * E / (lx2 * lx2 * ly2);
+        case SGPR_K_DYDY0DY0: return (3.0 * ly2 - dy * dy) * dy * E / (ly2 * ly2 * ly2);
+        default: return (ly2 - dy * dy) * dx * E / (lx2 * ly2 * ly2);
+        }
+    }
+}
+
+template <int FAM>
+__global__ void kernel_extra_kernel(int which, int m, const double *xa, const double *ya, const double *xb,
+                                    const double *yb, const KConst kc, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = extra_eval<FAM>(which, xa[i], ya[i], xb[i], yb[i], kc);
+}
+
 // K*(2 x 2n0) . alpha for one test point per workgroup (sympgpr.f90:75-86, :112-124 with
 // alpha = Kyinv ztrain cached): row 1 -> out_p, row 2 -> out_q.
 template <int FAM>
@@ -628,6 +684,14 @@ int kernel_eval(int family, int which, int m, const double *xa, const double *ya
                 const double *yb, const KConst &kc, double *out, hipStream_t st)
 {
     if (m <= 0) return 0;
+    if (which >= SGPR_K_DX && which <= SGPR_K_DXDY0DY0)
+        return dispatch_family(family, [&](auto fam) {
+            constexpr int F = decltype(fam)::value;
+            hipLaunchKernelGGL((kernel_extra_kernel<F>), dim3((m + 255) / 256), dim3(256), 0, st, which, m, xa, ya,
+                               xb, yb, kc, out);
+            SGPR_CHECK_LAUNCH();
+            return 0;
+        });
     const int deriv = which >> 2;
     which &= 3;
     if (deriv < 0 || deriv > 2) { set_error("unknown kernel function"); return SGPR_E_ARG; }

@@ -3,15 +3,17 @@ functions that enter the Gram matrix, `name_num(x_a, y_a, x_b, y_b, lx, ly[, p])
 the same device code the Gram kernels use (sgpr_kernel_eval_host).  Arguments may be scalars
 (-> float, like f2py) or broadcastable arrays (-> array, one batched launch).
 
-The eight length-scale derivatives build_dK / build_dKreg call (kernels.f90:133-231) are here
-as well (product kernels A, C, D).  The seven functions no caller in the reference uses (dkdx,
-dkdy, dkdx0, dkdy0 and the three d3k...dy0 functions, kernels.f90:12-57,95-132) are not mirrored."""
+All 19 functions of a generated kernels*.f90 are here: the four above, the eight length-scale
+derivatives build_dK / build_dKreg call (kernels.f90:133-231; product kernels A, C, D only -- the
+sum kernel's driver never differentiates with respect to l), and the seven no caller in the
+reference uses (dkdx, dkdy, dkdx0, dkdy0 and the three d3k...dy0 functions, kernels.f90:12-57,95-132)."""
 from . import _lib as L
 from . import ops
 
 __all__ = ["kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num", "dkdlx_num", "dkdly_num",
            "d3kdxdx0dlx_num", "d3kdydy0dlx_num", "d3kdxdy0dlx_num", "d3kdxdx0dly_num", "d3kdydy0dly_num",
-           "d3kdxdy0dly_num"]
+           "d3kdxdy0dly_num", "dkdx_num", "dkdy_num", "dkdx0_num", "dkdy0_num", "d3kdxdx0dy0_num",
+           "d3kdydy0dy0_num", "d3kdxdy0dy0_num"]
 
 
 def _eval(which, x_a, y_a, x_b, y_b, lx, ly, p):
@@ -73,3 +75,31 @@ def d3kdydy0dly_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:207-218
 
 def d3kdxdy0dly_num(x_a, y_a, x_b, y_b, lx, ly, p=None):   # kernels.f90:219-231
     return _eval(L.K_DXDY0 | L.K_DLY, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def dkdx_num(x_a, y_a, x_b, y_b, lx, ly, p=None):           # kernels.f90:12-23
+    return _eval(L.K_DX, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def dkdy_num(x_a, y_a, x_b, y_b, lx, ly, p=None):           # kernels.f90:24-34
+    return _eval(L.K_DY, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def dkdx0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):          # kernels.f90:35-46
+    return _eval(L.K_DX0, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def dkdy0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):          # kernels.f90:47-57
+    return _eval(L.K_DY0, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdxdx0dy0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):    # kernels.f90:95-107
+    return _eval(L.K_DXDX0DY0, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdydy0dy0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):    # kernels.f90:108-119
+    return _eval(L.K_DYDY0DY0, x_a, y_a, x_b, y_b, lx, ly, p)
+
+
+def d3kdxdy0dy0_num(x_a, y_a, x_b, y_b, lx, ly, p=None):    # kernels.f90:120-132
+    return _eval(L.K_DXDY0DY0, x_a, y_a, x_b, y_b, lx, ly, p)

@@ -368,3 +368,26 @@ def test_sections_replicas(oracle):
         assert np.linalg.norm(alphas[m] - a) / np.linalg.norm(a) < 1e-10
         assert nlls[m] == pytest.approx(nll, rel=1e-11)
     assert sections.owned_sections(5, 1, 2) == [1, 3]
+
+
+@pytest.mark.parametrize("fam", "ABCD")
+def test_all_19_kernel_functions_vs_reference_fixture(golden_dir, fam):
+    """The f2py `kernels` module, function for function, against the reference's compiled Fortran
+    (tests/golden/scalars.json); family D's length-scale derivatives included."""
+    import json
+    import os
+    from sympgpr_amd import kernels, ops
+    g = json.load(open(os.path.join(golden_dir, "scalars.json")))[fam]
+    a = {k: np.array(v) for k, v in g["args"].items()}
+    extra = (a["p"],) if fam == "D" else ()
+    with ops.family_scope(fam):
+        for name, ref in g["values"].items():
+            ref = np.array(ref, dtype=float)
+            if fam == "B" and ("dl" in name):
+                with pytest.raises(Exception):            # the sum kernel has no l-derivatives on the device
+                    getattr(kernels, name)(a["x_a"], a["y_a"], a["x_b"], a["y_b"], a["lx"][0], a["ly"][0])
+                continue
+            got = np.array([getattr(kernels, name)(a["x_a"][i], a["y_a"][i], a["x_b"][i], a["y_b"][i], a["lx"][i],
+                                                   a["ly"][i], *(e[i] for e in extra)) for i in range(len(ref))])
+            assert np.all(np.abs(got - ref) <= 1e-13 * np.maximum(np.abs(ref), 1e-3)), name
+    assert len(g["values"]) == 19 and len(kernels.__all__) == 19

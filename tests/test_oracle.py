@@ -195,3 +195,26 @@ def test_build_K_nd_against_sympy(oracle, fam, d):
                 for j in range(n0):
                     ref = sig * float(H[a][b](*X0[j], *X[i], *l))   # a = column ("0") point, as in build_K
                     assert K[a * n + i, b * n0 + j] == pytest.approx(ref, rel=1e-12, abs=1e-14)
+
+
+@pytest.mark.parametrize("fam", "ABCD")
+def test_all_generated_scalars_vs_reference_fixture(oracle, golden_dir, fam):
+    """tests/golden/scalars.json: all 19 functions of each kernels*.f90, evaluated by the
+    reference's compiled Fortran (make_scalar_golden.py).  The oracle restates the 4 Gram
+    functions (all families), the 8 length-scale derivatives (A, C) and the 7 unused ones."""
+    import json
+    from oracle.oracle import DL_NAMES, X_NAMES
+    g = json.load(open(os.path.join(golden_dir, "scalars.json")))[fam]
+    a = g["args"]
+    m = len(a["x_a"])
+    close = lambda v, r: abs(v - r) <= 1e-13 * max(abs(r), 1e-3)
+    for i in range(m):
+        pt = (a["x_a"][i], a["y_a"][i], a["x_b"][i], a["y_b"][i], a["lx"][i], a["ly"][i])
+        p = a["p"][i] if fam == "D" else 0.0
+        for w, name in enumerate(("kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num")):
+            assert close(oracle.scalar(fam, w, *pt, p), g["values"][name][i]), name
+        for w, name in X_NAMES.items():
+            assert close(oracle.scalar_x(fam, w, *pt, p), g["values"][name][i]), name
+        if fam in "AC":
+            for w, name in DL_NAMES.items():
+                assert close(oracle.scalar_dl(fam, w, *pt), g["values"][name][i]), name
