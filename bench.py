@@ -189,6 +189,12 @@ def main():
         aa = a.reshape(2 * d, n_pts).T[idx]
         resid = float(np.linalg.norm(pred + s2 * aa - zz) / np.linalg.norm(zz))
     nll = fit.nll()
+    # the Gram kernel alone, back to back (outside the timed region, not part of `value`): the build
+    # inside a step starts on an idle chip right after the barrier and carries that warm-up
+    rep = []
+    for _ in range(4):
+        fit.build()
+        rep.append(fit.stage_ms()[0])
     fit.close()
 
     gram_bytes = 8.0 * n * (n + 1) / 2 if args.lower_only else 8.0 * n * n
@@ -207,6 +213,8 @@ def main():
                    "triangle": "lower" if args.lower_only else "full"},
         "gram_gb_s": gram_bytes / (stage[0] * 1e-3) / 1e9,
         "gram_ms": stage[0],
+        "gram_repeat_ms": min(rep[1:]),
+        "gram_repeat_gb_s": (8.0 * n * (n + 1) / 2 if args.lower_only else 8.0 * n * n) / (min(rep[1:]) * 1e-3) / 1e9,
         "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12,
         "chol_ms": stage[1],
         "solve_ms": stage[2],
@@ -235,7 +243,9 @@ def main():
                            "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}
     out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel" if d == 1 else "gram_nd_kernel", "achieved": out["gram_gb_s"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["gram_gb_s"] / HBM_PEAK_GBS,
-                            "traffic": traffic.get("gram")}
+                            "traffic": traffic.get("gram"),
+                            "achieved_back_to_back": out["gram_repeat_gb_s"],
+                            "frac_back_to_back": out["gram_repeat_gb_s"] / HBM_PEAK_GBS}
     if args.cpu_sample > 0 and d == 1:
         cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family, args.cpu_sample)
         with SympFit(args.family, qs, Ps, zs, hs, s2s) as fs:
