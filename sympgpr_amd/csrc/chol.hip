@@ -439,7 +439,9 @@ struct Ctx {
 };
 
 int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0);
-inline int la_block(int n) { return n <= 8192 ? 256 : (n <= 24576 ? 512 : 1024); }
+// measured with the left-looking panel (factor ms at nb = 256 / 512 / 1024 / 2048): n = 8192 12.1 / 13.0 /
+// 15.2 / 20.1, 16384 49.6 / 43.9 / 46.8 / 56.5, 32768 307 / 250 / 228 / 229, 49152 964 / 770 / 682 / 656
+inline int la_block(int n) { return n <= 8192 ? 256 : (n <= 24576 ? 512 : (n <= 40960 ? 1024 : 2048)); }
 
 int trsm_rec(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, int off, const Ctx &c)
 {
@@ -598,13 +600,36 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
     };
     const hipStream_t su = c.st;
     Ctx cp{c.inv, c.dinfo, sp, 0};
+    // Panel k = diagonal block + everything below it, factored LEFT-looking leaf column by leaf
+    // column over its full height: fold the panel's earlier columns into column j (one product,
+    // k = 128 j), factor the 128 x 128 diagonal leaf, multiply the rows below by its inverse.
+    // 3 launches per leaf column (11 for nb = 512) where factoring the diagonal block recursively
+    // and then solving the rows below takes 19 -- on this stream every launch is a link of the
+    // serial chain the whole factorisation waits for.
+    static const bool left = [] { const char *e = getenv("SGPR_LA_PANEL"); return !(e && e[0] == 'r'); }();
     auto panel = [&](int k) -> int {   // on the P stream
-        const int k0 = k * nb, w = std::min(nb, n - k0), below = n - k0 - w;
+        const int k0 = k * nb, w = std::min(nb, n - k0), rows = n - k0, below = rows - w;
         double *Akk = A + k0 + (size_t)k0 * lda;
-        int rc = potrf_rec(w, Akk, lda, off0 + k0, cp);
-        if (rc) return rc;
-        if (below > 0) rc = trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
-        return rc;
+        if (!left) {
+            int rc = potrf_rec(w, Akk, lda, off0 + k0, cp);
+            if (rc) return rc;
+            if (below > 0) rc = trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
+            return rc;
+        }
+        for (int c0 = 0; c0 < w; c0 += LEAF) {
+            const int nj = std::min((int)LEAF, w - c0), mrows = rows - c0;
+            double *Pj = Akk + c0 + (size_t)c0 * lda;          // P[c0:, c0:c0+nj]
+            int rc;
+            if (c0 > 0 && (rc = gemm_nt(mrows, nj, c0, -1.0, Akk + c0, lda, Akk + c0, lda, 1.0, Pj, lda, 0, 0, sp)))
+                return rc;
+            double *invj = cp.inv + (size_t)((off0 + k0 + c0) / LEAF) * LEAF * LEAF;
+            hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(LT), 0, sp, nj, Pj, lda, invj, cp.dinfo, off0 + k0 + c0,
+                               (int)LEAF_FACTOR, (unsigned long long *)nullptr);
+            SGPR_CHECK_LAUNCH();
+            if (mrows > nj && (rc = gemm_nt(mrows - nj, nj, nj, 1.0, Pj + nj, lda, invj, LEAF, 0.0, Pj + nj, lda, 0, 0, sp)))
+                return rc;
+        }
+        return 0;
     };
     int rc;
     SGPR_HIP(hipEventRecord(ev[2 * nblk], su));                // the side stream joins the caller's stream ...

@@ -665,7 +665,6 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
         if (!g.tri) g.n_super = g.n_sr * g.n_sc;
         return (unsigned)(((g.n_super + 7) / 8) * 8 * SR * SC);
     };
-    (void)0;
     ProfRec rec{};
     if (g_prof.on) {
         // algorithmic flop of this launch: 2k per updated element (lower: on/below the diagonal)
