@@ -345,11 +345,26 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
         o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
     }
 
-    // epilogue: acc[i][j][r] is C(m = row0 + wm*64 + j*16 + l15, n = col0 + wn*64 + i*16 + 4r + l4)
+    // epilogue: acc[i][j][r] is C(m = row0 + wm*64 + j*16 + l15, n = col0 + wn*64 + i*16 + 4r + l4).
+    // Old values are fetched 16 at a time before any store (see gemm_body_dma: per-element
+    // read-modify-write compiles to 64 dependent round trips).
     const double alpha = g.alpha, beta = g.beta;
     const bool interior = (row0 + BM <= g.m) && (col0 + BN <= g.n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        double old[4][4];
+        if (beta != 0.0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = col0 + wn * 64 + i * 16 + 4 * r + l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = row0 + wm * 64 + j * 16 + l15;
+                    old[r][j] = (interior || (m < g.m && n < g.n)) ? g.C[(size_t)m + (size_t)n * g.ldc] : 0.0;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = col0 + wn * 64 + i * 16 + 4 * r + l4;
@@ -357,12 +372,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs &g, double *smem, int t
             for (int j = 0; j < 4; ++j) {
                 const int m = row0 + wm * 64 + j * 16 + l15;
                 if (interior || (m < g.m && n < g.n)) {
-                    double *c = g.C + (size_t)m + (size_t)n * g.ldc;
                     const double v = alpha * acc[i][j][r];
-                    *c = (beta == 0.0) ? v : __builtin_fma(beta, *c, v);
+                    g.C[(size_t)m + (size_t)n * g.ldc] = (beta == 0.0) ? v : __builtin_fma(beta, old[r][j], v);
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -561,20 +576,30 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
     }
 
     // interior tile: no bounds checks.  acc[i][j][r] is C(row0 + wm*64 + j*16 + l15, col0 + wn*64 + i*16 + 4r + l4)
+    // The old values of C are fetched 16 at a time BEFORE any of them is overwritten: written as
+    // `*c = fma(beta, *c, v)` per element, hipcc cannot rule out aliasing between one element's store
+    // and the next one's load and emits 64 dependent load -> wait -> store round trips per thread
+    // (~50 us per tile, the whole fixed cost of a short-k launch: k = 512 ran at 42 TFLOP/s).
     const double alpha = g.alpha, beta = g.beta;
+    double *const cbase = g.C + (size_t)(row0 + wm * 64 + l15) + (size_t)(col0 + wn * 64 + l4) * g.ldc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        double old[4][4];
+        if (beta != 0.0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = col0 + wn * 64 + i * 16 + 4 * r + l4;
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) old[r][j] = cbase[(size_t)(j * 16) + (size_t)(i * 16 + 4 * r) * g.ldc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int m = row0 + wm * 64 + j * 16 + l15;
-                double *c = g.C + (size_t)m + (size_t)n * g.ldc;
                 const double v = alpha * acc[i][j][r];
-                *c = (beta == 0.0) ? v : __builtin_fma(beta, *c, v);
+                cbase[(size_t)(j * 16) + (size_t)(i * 16 + 4 * r) * g.ldc] = (beta == 0.0) ? v : __builtin_fma(beta, old[r][j], v);
             }
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
