@@ -17,6 +17,7 @@
 //     the accumulator then has lane&15 = m (memory-contiguous in column-major C) and
 //     4*reg+(lane>>4) = n, so every C access of a 16-lane quarter is one full 128-B line.
 //     (fp64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg -- NOT the f32 map.)
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
