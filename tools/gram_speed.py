@@ -1,10 +1,13 @@
-"""Gram-build time: the one-pair kernel (gram_pairs) vs the general-d kernel run at d = 1.
+"""Gram-build time: the one-pair kernel (gram_pairs) vs the general-d kernel run at d = 1, back to
+back and after an idle gap (what a bench step sees right after its barrier).
 python tools/gram_speed.py [N]"""
 import ctypes as C
+import os
 import sys
+import time
 import numpy as np
 import torch
-sys.path.insert(0, "."); sys.path.insert(0, "..")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sympgpr_amd import _lib as L
 from sympgpr_amd.dist import HipOps
 from bench import synth
@@ -16,9 +19,12 @@ A = ops.empty(n * n)
 dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
 x, y = dev(q), dev(P)
 X = dev(np.concatenate([q, P]))
-def timeit(fn):
+def timeit(fn, gap=0.0):
     ts = []
     for _ in range(4):
+        if gap:
+            torch.cuda.synchronize()
+            time.sleep(gap)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
@@ -27,3 +33,7 @@ t1 = timeit(lambda: ops.gram_pairs("A", N, N, x, y, x, y, hyp, A, [0, N, N * n, 
 t2 = timeit(lambda: ops.gram_nd("A", 1, N, N, X, X, hyp, A, n))
 for name, ts in (("gram_pairs", t1), ("gram_nd d=1", t2)):
     print("%-12s %s ms -> %.0f GB/s" % (name, ["%.2f" % t for t in ts], 8.0 * n * n / min(ts) / 1e6))
+for gap in (0.001, 0.05, 0.5):
+    t1 = timeit(lambda: ops.gram_pairs("A", N, N, x, y, x, y, hyp, A, [0, N, N * n, N + N * n], n, L.G_ALL), gap)
+    t2 = timeit(lambda: ops.gram_nd("A", 1, N, N, X, X, hyp, A, n), gap)
+    print("idle %.3f s before each build: gram_pairs %s ms, gram_nd %s ms" % (gap, ["%.2f" % t for t in t1], ["%.2f" % t for t in t2]))
