@@ -15,6 +15,7 @@
 // inv(L_leaf) -- i.e. GEMM work on the matrix cores instead of a substitution.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -585,10 +586,14 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
     int dev = 0;
     SGPR_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
-    if (!side[dev]) {
-        int lo = 0, hi = 0;
-        SGPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        SGPR_HIP(hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi));
+    {
+        static std::mutex mu;                       // two fit handles may factor for the first time at once
+        std::lock_guard<std::mutex> lock(mu);
+        if (!side[dev]) {
+            int lo = 0, hi = 0;
+            SGPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            SGPR_HIP(hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi));
+        }
     }
     const hipStream_t sp = side[dev];
     const int nblk = (n + nb - 1) / nb;
