@@ -442,7 +442,7 @@ struct Ctx {
 int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0);
 // measured with the left-looking panel (factor ms at nb = 256 / 512 / 1024 / 2048): n = 8192 12.1 / 13.0 /
 // 15.2 / 20.1, 16384 49.6 / 43.9 / 46.8 / 56.5, 32768 307 / 250 / 228 / 229, 49152 964 / 770 / 682 / 656
-inline int la_block(int n) { return n <= 8192 ? 256 : (n <= 24576 ? 512 : (n <= 40960 ? 1024 : 2048)); }
+inline int la_block(int n) { return n <= 4096 ? 256 : (n <= 24576 ? 512 : (n <= 40960 ? 1024 : 2048)); }
 
 int trsm_rec(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, int off, const Ctx &c)
 {
@@ -605,13 +605,16 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
     };
     const hipStream_t su = c.st;
     Ctx cp{c.inv, c.dinfo, sp, 0};
-    // Panel k = diagonal block + everything below it, factored LEFT-looking leaf column by leaf
-    // column over its full height: fold the panel's earlier columns into column j (one product,
-    // k = 128 j), factor the 128 x 128 diagonal leaf, multiply the rows below by its inverse.
+    // Panel k = diagonal block + everything below it, factored leaf column by leaf column over its
+    // full height: factor the 128 x 128 diagonal leaf, multiply the rows below by its inverse, fold
+    // that column into the panel's remaining columns (one lower-trapezoid product, k = 128).
     // 3 launches per leaf column (11 for nb = 512) where factoring the diagonal block recursively
     // and then solving the rows below takes 19 -- on this stream every launch is a link of the
-    // serial chain the whole factorisation waits for.
-    static const bool left = [] { const char *e = getenv("SGPR_LA_PANEL"); return !(e && e[0] == 'r'); }();
+    // serial chain the whole factorisation waits for.  SGPR_LA_PANEL=l folds left-looking instead
+    // (column j collects columns 0..j-1 in one product of growing k: n = 16384 39.4 vs 37.9 ms),
+    // =r is the recursive form (43.9 -> 48.7 ms before the epilogue fix).
+    static const int pmode = [] { const char *e = getenv("SGPR_LA_PANEL"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
+    const bool left = pmode != 2, right_in = pmode == 0;
     auto panel = [&](int k) -> int {   // on the P stream
         const int k0 = k * nb, w = std::min(nb, n - k0), rows = n - k0, below = rows - w;
         double *Akk = A + k0 + (size_t)k0 * lda;
@@ -625,13 +628,18 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
             const int nj = std::min((int)LEAF, w - c0), mrows = rows - c0;
             double *Pj = Akk + c0 + (size_t)c0 * lda;          // P[c0:, c0:c0+nj]
             int rc;
-            if (c0 > 0 && (rc = gemm_nt(mrows, nj, c0, -1.0, Akk + c0, lda, Akk + c0, lda, 1.0, Pj, lda, 0, 0, sp)))
+            if (!right_in && c0 > 0 &&
+                (rc = gemm_nt(mrows, nj, c0, -1.0, Akk + c0, lda, Akk + c0, lda, 1.0, Pj, lda, 0, 0, sp)))
                 return rc;
             double *invj = cp.inv + (size_t)((off0 + k0 + c0) / LEAF) * LEAF * LEAF;
             hipLaunchKernelGGL(leaf_kernel, dim3(1), dim3(LT), 0, sp, nj, Pj, lda, invj, cp.dinfo, off0 + k0 + c0,
                                (int)LEAF_FACTOR, (unsigned long long *)nullptr);
             SGPR_CHECK_LAUNCH();
             if (mrows > nj && (rc = gemm_nt(mrows - nj, nj, nj, 1.0, Pj + nj, lda, invj, LEAF, 0.0, Pj + nj, lda, 0, 0, sp)))
+                return rc;
+            const int ncols = w - c0 - nj;
+            if (right_in && ncols > 0 &&
+                (rc = gemm_nt(mrows - nj, ncols, nj, -1.0, Pj + nj, lda, Pj + nj, lda, 1.0, Pj + nj + (size_t)nj * lda, lda, 1, 0, sp)))
                 return rc;
         }
         return 0;
