@@ -1,0 +1,41 @@
+"""Randomised sizes through the host-level factor / solve / Gram entry points: ragged tiles, every
+driver switch-over (leaf, look-ahead block sizes, recursion), the triangular tile map."""
+import numpy as np
+import pytest
+import scipy.linalg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_sizes_factor_and_solve():
+    from sympgpr_amd import ops
+    rng = np.random.default_rng(2026)
+    sizes = sorted(set([1, 2, 127, 128, 129, 255, 256, 257, 511, 512, 513, 640, 1023, 1025, 2047, 2049, 4097] +
+                       list(rng.integers(3, 6000, 28))))
+    for n in sizes:
+        B = rng.standard_normal((n, n + 3))
+        A = B @ B.T / n + 0.5 * np.eye(n)
+        Lg = ops.cholesky(A)
+        Lr = scipy.linalg.cholesky(A, lower=True)
+        assert np.abs(Lg - Lr).max() <= 1e-11 * np.abs(Lr).max(), n
+        assert np.all(np.triu(Lg, 1) == 0)
+        for nrhs in (1, 9):
+            b = rng.standard_normal((n, nrhs)) if nrhs > 1 else rng.standard_normal(n)
+            x = ops.solve_cholesky(Lg, b)
+            xr = scipy.linalg.cho_solve((Lr, True), b)
+            assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr), (n, nrhs)
+
+
+def test_random_shapes_gram(oracle):
+    from sympgpr_amd import ops
+    rng = np.random.default_rng(77)
+    for _ in range(12):
+        n, n0 = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+        fam = "ABCD"[int(rng.integers(0, 4))]
+        x, y = rng.uniform(0, 6.3, n), rng.uniform(-3, 3, n)
+        x0, y0 = rng.uniform(0, 6.3, n0), rng.uniform(-3, 3, n0)
+        hyp = [0.4, 0.9, 0.6, 1.2] if fam == "D" else [0.4, 0.9, 1.2]
+        K = np.full((2 * n, 2 * n0), np.nan, order="F")
+        ops.build_k(x, y, x0, y0, hyp, K, family=fam)
+        Ko = oracle.build_K(fam, x, y, x0, y0, hyp)
+        assert np.all(np.abs(K - Ko) <= 4e-15 * np.abs(Ko).max() + 3e-13 * np.abs(Ko)), (fam, n, n0)
