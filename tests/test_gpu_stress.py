@@ -39,3 +39,20 @@ def test_random_shapes_gram(oracle):
         ops.build_k(x, y, x0, y0, hyp, K, family=fam)
         Ko = oracle.build_K(fam, x, y, x0, y0, hyp)
         assert np.all(np.abs(K - Ko) <= 4e-15 * np.abs(Ko).max() + 3e-13 * np.abs(Ko)), (fam, n, n0)
+
+
+def test_random_sizes_fit(oracle):
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(5)
+    for N in sorted(set([1, 2, 63, 64, 65, 255, 257] + list(rng.integers(3, 1400, 10)))):
+        fam = "ABCD"[int(rng.integers(0, 4))]
+        q, P, z = rng.uniform(0, 6.3, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+        l = 2.0 * np.sqrt(12 * np.pi / max(N, 4))
+        hyp = [l, l, 0.5, 1.0] if fam == "D" else [l, l, 1.0]
+        s2 = 1e-2 / l**2
+        with SympFit(fam, q, P, z, hyp, s2, lower_only=bool(N % 2)) as f:
+            a = f.run().alpha()
+            nll = f.nll()
+        ao, nllo, _ = oracle.fit(fam, q, P, z, hyp, s2)
+        assert np.linalg.norm(a - ao) <= 1e-10 * np.linalg.norm(ao), (fam, N)
+        assert nll == pytest.approx(nllo, rel=1e-10), (fam, N)
