@@ -42,15 +42,14 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 //   factor : 16x16 diagonal block by one wave (row per lane, pivots/columns via shuffles) ->
 //            panel rows solved one per thread against it -> rank-16 update of the trailing
 //            lower triangle in 4x4 register tiles;
-//   inverse: LAPACK dtrtri order (last panel first): X21 = -X22 L21 inv(L11) with one row per
-//            thread, inv(L11) by 16 lanes of wave 0.
+//   inverse: the eight 16x16 diagonal blocks at once, then recursive doubling (16 -> 32 -> 64 -> 128):
+//            X21 = -X22 L21 X11 for every pair of a level on the matrix cores.
 __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda, double *inv,
                                                   int *dinfo, int goff, int mode,
                                                   unsigned long long *stamps)
 {
     __shared__ double s[LEAF * LLD];
     __shared__ double sInv[PW * (PW + 1)];
-    __shared__ double sT[(LEAF - PW) * (PW + 1)];   // T = X22 L21 strip of the inverse phase
     __shared__ double sRl[PW];                      // 1 / L11(j,j) of the current panel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -238,54 +237,65 @@ __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda,
         __syncthreads();
     }
     mark(5);
-    // (I1) per panel: T = X22 L21 in 4x2 register tiles (224 threads), through the sT strip, then
-    //      X21 = -T inv(L11) with inv(L11) read from the (already inverted) diagonal block.
-    for (int c0 = LEAF - 2 * PW; c0 >= 0; c0 -= PW) {
-        const int r0 = c0 + PW;
-        const int rem = LEAF - r0;            // rows below the panel's diagonal block, multiple of 16
-        const int nt = rem / 16;
+    // (I1) recursive doubling: with the diagonal blocks of size b inverted, the blocks of size 2b follow
+    //      from X21 = -X22 L21 X11 for every pair at once -- three levels (b = 16, 32, 64), two small
+    //      matrix products each, instead of seven dependent panel steps (12.4 -> ~6 us).  The product
+    //      T = X22 L21 is parked in the strictly upper corner of s (rows 0..63, columns 64..127),
+    //      which nothing reads: the write-back below masks the upper triangle.
+    {
         const int wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-        // T = X22 L21: row tile `it` needs k = r0 .. its own last row (X22 lower triangular; the
-        // strict upper part of its diagonal block is masked to zero)
-        for (int idx = wave; idx < nt; idx += LT / 64) {
-            const int it = nt - 1 - idx;                      // heaviest tiles first
-            const int i = r0 + 16 * it + l15;
-            // 16 k per trip: the eight LDS reads of a trip are issued together and two accumulator
-            // chains alternate (a one-step loop is a chain of LDS + MFMA latencies)
-            double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            for (int kb = r0; kb < r0 + 16 * (it + 1); kb += 16) {
-                double xa[4], lb[4];
+        double *const scr = s + (LEAF / 2) * LLD;                 // scr[c * LLD + r], r < 64, c < 64
+        for (int b = PW; b < LEAF; b *= 2) {
+            const int tb = b / 16, per = tb * tb, ntiles = (LEAF / (2 * b)) * per;
+            // T = X22 L21 (X22 lower triangular: k <= row)
+            for (int t = wave; t < ntiles; t += LT / 64) {
+                const int p = t / per, tt = t - p * per, ti = tb - 1 - tt % tb, tj = tt / tb;   // heavy row tiles first
+                const int o = 2 * b * p, o2 = o + b;
+                const int row = 16 * ti + l15;
+                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                for (int kb = 0; kb < 16 * (ti + 1); kb += 16) {
+                    double xa[4], lb[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = kb + 4 * u + l4;
-                    xa[u] = (k <= i) ? s[k * LLD + i] : 0.0;
-                    lb[u] = s[(c0 + l15) * LLD + k];
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kb + 4 * u + l4;
+                        xa[u] = (k <= row) ? s[(o2 + k) * LLD + o2 + row] : 0.0;
+                        lb[u] = s[(o + 16 * tj + l15) * LLD + o2 + k];
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], lb[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], lb[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], lb[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], lb[3], acc1, 0, 0, 0);
                 }
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], lb[0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], lb[1], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], lb[2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], lb[3], acc1, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scr[(16 * tj + l15) * LLD + b * p + 16 * ti + 4 * r + l4] = acc0[r] + acc1[r];
             }
+            __syncthreads();
+            mark(6);
+            // X21 = -T X11 (X11 lower triangular: k >= column), written over L21
+            for (int t = wave; t < ntiles; t += LT / 64) {
+                const int p = t / per, tt = t - p * per, ti = tt % tb, tj = tt / tb;
+                const int o = 2 * b * p, o2 = o + b;
+                const int col = 16 * tj + l15;
+                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                for (int kb = 16 * tj; kb < b; kb += 16) {
+                    double ta[4], xb[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sT[(16 * it + 4 * r + l4) * (PW + 1) + l15] = acc0[r] + acc1[r];
-        }
-        __syncthreads();
-        mark(6);
-        // X21 = -T inv(L11): inv(L11) sits in the (already inverted) diagonal block, lower triangular
-        for (int it = wave; it < nt; it += LT / 64) {
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int u = 0; u < 4; ++u) {
+                        const int k = kb + 4 * u + l4;
+                        ta[u] = scr[k * LLD + b * p + 16 * ti + l15];
+                        xb[u] = (k >= col) ? s[(o + col) * LLD + o + k] : 0.0;
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[0], xb[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[1], xb[1], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[2], xb[2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[3], xb[3], acc1, 0, 0, 0);
+                }
 #pragma unroll
-            for (int kk = 0; kk < PW / 4; ++kk) {
-                const int k = 4 * kk + l4;
-                const double ta = sT[(16 * it + l15) * (PW + 1) + k];
-                const double xb = (k >= l15) ? s[(c0 + l15) * LLD + c0 + k] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, xb, acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) s[(o + col) * LLD + o2 + 16 * ti + 4 * r + l4] = -(acc0[r] + acc1[r]);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[(c0 + l15) * LLD + r0 + 16 * it + 4 * r + l4] = -acc[r];
+            __syncthreads();
+            mark(5);
         }
-        __syncthreads();
-        mark(5);
     }
 #pragma unroll 8
     for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
