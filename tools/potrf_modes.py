@@ -2,7 +2,7 @@
 (run once per mode: SGPR_POTRF=rec|la, SGPR_POTRF_NB=...)"""
 import os, sys
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "..")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sympgpr_amd.fit import SympFit
 from bench import synth
 for N in [int(a) for a in sys.argv[1:]]:

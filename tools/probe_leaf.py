@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sympgpr_amd import _lib as L
 lib = L.load_library()
 o = np.zeros(8)

@@ -1,6 +1,6 @@
 import ctypes as C, sys
 import numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "..")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from sympgpr_amd import _lib as L
 lib = L.load_library()
 n = 2048
