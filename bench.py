@@ -93,25 +93,78 @@ def cpu_baseline(family, n_pts_sample):
     }, alpha, (q, P, z, hyp, s2)
 
 
+def kernel_code_hash():
+    """Identifies the kernel sources a PMC traffic profile belongs to (bench.py reports `traffic` only
+    from a profile taken with exactly these sources)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("gemm_f64.hip", "gemm_tile.h", "chol.hip", "gram.hip", "gram_nd.hip"):
+        with open(os.path.join(ROOT, "sympgpr_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def load_traffic(n_pts, d, family, lower_only):
+    """HBM-side bytes per launch from the committed separate `rocprofv3 --pmc` passes of this same
+    configuration (newest profiles/rNN first).  Returns ({}, None) when there is none or when the
+    kernels have changed since it was taken."""
+    import glob
+    code = kernel_code_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_*.json")), reverse=True):
+        try:
+            pm = json.load(open(path))
+        except Exception:
+            continue
+        c = pm.get("config", {})
+        if (c.get("n_pts") == n_pts and c.get("family") == family and c.get("pairs_per_point", 1) == d
+                and c.get("triangle", "full") == ("lower" if lower_only else "full") and pm.get("code_hash") == code):
+            out = {}
+            for key, name in (("gemm", "gemm_nt_kernel<256, 128>"), ("gram", "gram_pairs_kernel"), ("gram", "gram_nd_kernel")):
+                if name in pm:
+                    out[key] = pm[name]["traffic_bytes_per_launch"]
+            return out, "%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, kernels %s)" % (
+                os.path.relpath(path, ROOT), code)
+    return {}, None
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` typed by hand: start the N ranks as fresh child processes BEFORE
+    anything in this process touches the GPU (a process that has initialised HIP must never be
+    replaced or forked into ranks).  Returns the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2N)")
+    ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2*d*N)")
     ap.add_argument("--family", default="A")
     ap.add_argument("--d", type=int, default=1,
                     help="canonical pairs per training point (matrix order n = 2*d*N); 1 = the reference's "
-                         "(q, P) layout, 2 / 3 = BASELINE configs 03_henon_heiles / 05_tokamak")
+                         "(q, P) layout, 2 / 3 = BASELINE configs 03_henon_heiles / 05_tokamak; N = 65536 with "
+                         "--d 2 is the n = 262144 multi-GPU configuration")
     ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--nb", type=int, default=2048, help="block size of the multi-GPU block-cyclic layout")
     ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
     ap.add_argument("--no-launch-events", action="store_true",
-                    help="skip the per-launch HIP-event timing of the GEMM kernel (use under rocprofv3 --pmc)")
+                    help="skip the extra untimed pass that times every GEMM launch with HIP events")
     ap.add_argument("--lower-only", action="store_true",
                     help="build only the lower triangle of K (what the factor reads) instead of the "
                          "full matrix build_K defines")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))     # nothing above has touched the GPU
 
     import torch
     import sympgpr_amd
@@ -120,12 +173,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
-    if sympgpr_amd.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: libsympgpr_hip.so has no CPU fallback")
+    if sympgpr_amd.device_count() < max(1, min(args.gpus, world)):
+        raise SystemExit("bench.py --gpus %d needs %d GPU(s), this box shows %d: libsympgpr_hip.so has no CPU fallback"
+                         % (args.gpus, args.gpus, sympgpr_amd.device_count()))
+    if local_rank >= sympgpr_amd.device_count():
+        raise SystemExit("rank %d: needs %d GPUs, this box shows %d" % (rank, world, sympgpr_amd.device_count()))
     torch.cuda.set_device(local_rank)
     lib = L.load_library()
     L.check(lib.sgpr_set_device(local_rank))
@@ -146,13 +198,14 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
         from sympgpr_amd.dist_bench import run_distributed
         return run_distributed(args, rank, local_rank, world, synth, METRIC,
-                               {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS}, synth_pairs)
+                               {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS}, synth_pairs, cpu_baseline)
 
     n_pts = args.n_pts
     d = args.d
     n = 2 * d * n_pts
     if d == 1:
         q, P, z, hyp, s2 = synth(n_pts)
+        X = np.column_stack((q, P))
         fit = SympFit(args.family, q, P, z, hyp, s2, lower_only=args.lower_only)
     else:
         X, z, hyp, s2 = synth_pairs(n_pts, d)
@@ -161,21 +214,27 @@ def main():
     for _ in range(args.warmup):
         fit.run()
     stage = np.zeros(3)
-    prof = np.zeros(8)
     barrier()
-    if not args.no_launch_events:
-        L.check(lib.sgpr_profile_begin())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         fit.run()
         stage += np.array(fit.stage_ms())
     barrier()
     dt = time.perf_counter() - t0
-    L.check(lib.sgpr_profile_end(L.dptr(prof)))
     stage /= max(args.steps, 1)
     ms_per_step = dt / args.steps * 1e3
 
-    # parity evidence at full size: Ky alpha == z through the independent K*-row kernel
+    # roofline pass: ONE more step, outside the timed region, with a HIP-event pair (from a fixed
+    # pool) around every launch of the MFMA kernel on the stream it is launched on
+    prof = np.zeros(12)
+    if not args.no_launch_events:
+        L.check(lib.sgpr_profile_begin())
+        fit.run()
+        torch.cuda.synchronize()
+        L.check(lib.sgpr_profile_end(L.dptr(prof)))
+
+    # parity evidence at full size: Ky alpha == z through the device's K*-row kernel (the host-side
+    # re-evaluation of those rows by the oracle is part of the cpu_baseline leg below)
     a = fit.alpha()
     m = min(n_pts, 2048)
     idx = np.random.default_rng(0).choice(n_pts, m, replace=False)
@@ -218,41 +277,55 @@ def main():
         "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12,
         "chol_ms": stage[1],
         "solve_ms": stage[2],
+        "solve_gb_s": 8.0 * n * n / (stage[2] * 1e-3) / 1e9,
         "residual_Ky_alpha_minus_z": resid,
         "nll": nll,
     }
-    # HBM-side traffic per launch comes from the committed PMC passes of this same configuration
-    # (rocprofv3 --pmc crashes when combined with the per-launch HIP events used here, so it is a
-    # separate run: profiles/r01/pmc_traffic_n131072.json); null for any other configuration.
-    traffic = {}
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic_n131072.json")))
-        if pm["config"]["n_pts"] == n_pts and pm["config"]["family"] == args.family and not args.lower_only and d == 1:
-            traffic = {"gemm": pm["gemm_nt_kernel<256, 128>"]["traffic_bytes_per_launch"],
-                       "gram": pm["gram_pairs_kernel"]["traffic_bytes_per_launch"]}
-    except Exception:
-        pass
-    big_n, big_flop, big_ms = prof[0], prof[1], prof[2]
-    if big_n > 0 and big_ms > 0:
-        ach = big_flop / (big_ms * 1e-3) / 1e12
+    traffic, traffic_source = load_traffic(n_pts, d, args.family, args.lower_only)
+    alone_n, alone_flop, alone_ms = prof[0], prof[1], prof[2]
+    ov_n, ov_flop, ov_ms = prof[8], prof[9], prof[10]
+    if alone_n + ov_n > 0:
+        # `achieved` = launches that had the device to themselves (sum of their durations <= wall time);
+        # the launches of the look-ahead driver run two streams at once and are reported beside it
+        base_n, base_flop, base_ms = (alone_n, alone_flop, alone_ms) if alone_n > 0 else (ov_n, ov_flop, ov_ms)
+        ach = base_flop / (base_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (fp64 MFMA trailing update)",
                            "achieved": ach, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
                            "frac": ach / MFMA_F64_PEAK_TF, "traffic": traffic.get("gemm"),
-                           "launches": int(big_n), "flop_per_launch": big_flop / big_n,
-                           "avg_launch_ms": big_ms / big_n,
+                           "traffic_source": traffic_source,
+                           "timing": "one untimed extra step, HIP-event pair per launch on the launch stream",
+                           "launches": int(base_n), "flop_per_launch": base_flop / base_n,
+                           "avg_launch_ms": base_ms / base_n,
+                           "launches_alone": int(alone_n), "launches_overlapped": int(ov_n),
+                           "achieved_overlapped": (ov_flop / (ov_ms * 1e-3) / 1e12) if ov_ms > 0 else None,
+                           "achieved_all_launches": (alone_flop + ov_flop) / ((alone_ms + ov_ms) * 1e-3) / 1e12,
+                           "sum_launch_ms_alone": alone_ms, "sum_launch_ms_overlapped": ov_ms,
+                           "launches_untimed": int(prof[11]),
                            "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}
     out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel" if d == 1 else "gram_nd_kernel", "achieved": out["gram_gb_s"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["gram_gb_s"] / HBM_PEAK_GBS,
-                            "traffic": traffic.get("gram"),
+                            "traffic": traffic.get("gram"), "traffic_source": traffic_source,
                             "achieved_back_to_back": out["gram_repeat_gb_s"],
                             "frac_back_to_back": out["gram_repeat_gb_s"] / HBM_PEAK_GBS}
-    if args.cpu_sample > 0 and d == 1:
-        cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family, args.cpu_sample)
-        with SympFit(args.family, qs, Ps, zs, hs, s2s) as fs:
+    if args.cpu_sample > 0:
+        cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family if d == 1 else "A", args.cpu_sample)
+        with SympFit(args.family if d == 1 else "A", qs, Ps, zs, hs, s2s) as fs:
             a_gpu = fs.run().alpha()
         out["alpha_rel_err"] = float(np.linalg.norm(a_gpu - a_ref) / np.linalg.norm(a_ref))
         out["alpha_rel_err_at"] = "n=%d vs the CPU baseline's solve" % (2 * args.cpu_sample)
         out["cpu_baseline"] = cb
+        # the checker's second job: rows of Ky at full size re-evaluated on the host by the oracle
+        # (restated Fortran formulas), so the full-size residual does not rest on any device formula
+        from oracle.oracle import Oracle
+        orc = Oracle()
+        ids = idx[:128]
+        if d == 1:
+            Krows = orc.build_K(args.family, q[ids], P[ids], q, P, hyp, threads=min(8, os.cpu_count() or 1))
+        else:
+            Krows = orc.build_K_nd(args.family, X[ids], X, hyp)
+        rows = np.concatenate([b * n_pts + ids for b in range(2 * d)])
+        rr = Krows @ a + s2 * a[rows] - z[rows]
+        out["residual_oracle_rows"] = float(np.linalg.norm(rr) / np.linalg.norm(z[rows]))
     print(json.dumps(out))
 
 

@@ -266,33 +266,17 @@ int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, dou
                        void *stream);
 
 /* Per-launch HIP-event timing of the MFMA GEMM kernel between begin and end (measurement
- * aid for bench.py's roofline leg; not part of the reference's interface).
- * out8: [0..2] launches / algorithmic flop / ms of the 256x128-tile kernel, [3..5] same for the
- * 128x128-tile kernel, [6..7] flop / ms of the single largest launch. */
+ * aid for bench.py's roofline pass; not part of the reference's interface).  Events come from a
+ * fixed pool (8192 launches per window; further launches are counted, not timed).
+ * out12: [0..2] launches / algorithmic flop / ms of the 256x128-tile kernel for launches that had
+ * the device to themselves, [3..5] all launches of the smaller tile shapes, [6..7] flop / ms of the
+ * single largest launch, [8..10] 256x128-tile launches issued by the look-ahead driver (two streams
+ * share the chip, their durations overlap), [11] launches beyond the pool. */
 int sgpr_profile_begin(void);
-int sgpr_profile_end(double *out8);
-/* per-launch records of the window closed by the last sgpr_profile_end: 6 doubles each
- * (m, n, k, lower, big-tile flag, ms); returns the number of records available */
+int sgpr_profile_end(double *out12);
+/* per-launch records of the window closed by the last sgpr_profile_end: 7 doubles each
+ * (m, n, k, lower, big-tile flag, ms, overlap flag); returns the number of records available */
 int sgpr_profile_launches(double *buf, int max_records);
-
-/* Roofline calibration probes (measurement aids): a register-only fp64 MFMA issue loop with
- * `waves_per_simd` waves on every SIMD, and a streaming 16-B/lane write of `bytes` bytes. */
-int sgpr_probe_mfma_f64(int waves_per_simd, int iters, double *tflops);
-int sgpr_probe_hbm_write(size_t bytes, int reps, double *gbs);
-/* out3: TFLOP/s, shader cycles per MFMA per SIMD, shader clock (GHz) held during the loop */
-int sgpr_probe_mfma_clock(int nacc, int waves_per_simd, int iters, double *out3);
-/* one synthetic C -= A B^T with per-workgroup stamps: TFLOP/s, median k-loop cycles per
- * workgroup, median shader clock (GHz), k-steps per workgroup */
-int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4);
-/* probe switches for sgpr_probe_gemm: 8 = 128x128 tile shape, 16 = register-staged body; 0 = normal */
-int sgpr_probe_gemm_debug(int bits);
-/* shader cycles per phase of one 128x128 leaf factorisation: load, diag block, panel rows,
- * trailing update, write-back, inverse diag, inverse rows, final store */
-int sgpr_probe_leaf(double *out8);
-/* HW_REG_XCC_ID of each workgroup of a 1-D grid of 512-thread blocks (checks the tile map's `id % 8`) */
-int sgpr_probe_xcc(int nblocks, int *host_out);
-/* the same on a stream restricted by a CU mask (hipExtStreamCreateWithCUMask): out[2b] = XCC id, out[2b+1] = HW_ID */
-int sgpr_probe_cumask(const unsigned *mask_words, int nwords, int nblocks, int *host_out);
 
 #ifdef __cplusplus
 }

@@ -82,14 +82,6 @@ SIGNATURES = {
     "sgpr_trsm_rlt_dev": (C.c_int, [C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_gemm_nt_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t,
                                    C.c_double, _vp, C.c_size_t, C.c_int, C.c_long, _vp]),
-    "sgpr_probe_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
-    "sgpr_probe_mfma_clock": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
-    "sgpr_probe_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
-    "sgpr_probe_gemm_debug": (C.c_int, [C.c_int]),
-    "sgpr_probe_leaf": (C.c_int, [_dp]),
-    "sgpr_probe_cumask": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.POINTER(C.c_int)]),
-    "sgpr_probe_xcc": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
-    "sgpr_probe_hbm_write": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "sgpr_profile_begin": (C.c_int, []),
     "sgpr_profile_end": (C.c_int, [_dp]),
     "sgpr_profile_launches": (C.c_int, [_dp, C.c_int]),
@@ -107,7 +99,20 @@ SIGNATURES = {
     "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
 }
 
+# include/sympgpr_probe.h: measurement aids in their own library (never loaded by a product path)
+PROBE_SIGNATURES = {
+    "sgpr_probe_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "sgpr_probe_mfma_clock": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp]),
+    "sgpr_probe_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+    "sgpr_probe_gemm_debug": (C.c_int, [C.c_int]),
+    "sgpr_probe_leaf": (C.c_int, [_dp]),
+    "sgpr_probe_cumask": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "sgpr_probe_xcc": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "sgpr_probe_hbm_write": (C.c_int, [C.c_size_t, C.c_int, _dp]),
+}
+
 _LIB = None
+_PROBE = None
 
 
 def load_library():
@@ -137,6 +142,25 @@ def load_library():
     if lib.sgpr_abi_version() != 1:
         raise SympGPRError("ABI version mismatch")
     _LIB = lib
+    return lib
+
+
+def load_probe_library():
+    """libsympgpr_probe.so (include/sympgpr_probe.h): calibration probes and kernel diagnostics for
+    tools/ and bench.py's roofline calibration.  Links against libsympgpr_hip.so."""
+    global _PROBE
+    if _PROBE is not None:
+        return _PROBE
+    load_library()
+    path = os.path.join(os.path.dirname(lib_path()), "libsympgpr_probe.so")
+    if not os.path.exists(path):
+        raise SympGPRError("%s is missing: run make -C sympgpr_amd/csrc" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in PROBE_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _PROBE = lib
     return lib
 
 

@@ -265,7 +265,7 @@ int sgpr_potrf_host(int n, double *A, size_t lda)
     int info = 0;
     SGPR_HIP(hipMemcpyAsync(&info, dI.p, sizeof(int), hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipStreamSynchronize(st));
-    if (info) return info;
+    if (info) return info_status(info);
     SGPR_HIP(hipMemcpy2D(A, lda * sizeof(double), dA.p, ld * sizeof(double), ld * sizeof(double), n,
                          hipMemcpyDeviceToHost));
     return 0;
@@ -522,7 +522,7 @@ int sgpr_fit_factor(sgpr_fit_t f)
     SGPR_HIP(hipMemcpyAsync(&f->info, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
     f->factored = f->info == 0;
-    return f->info;
+    return info_status(f->info);
 }
 
 int sgpr_fit_solve(sgpr_fit_t f)
@@ -967,11 +967,11 @@ int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hy
     return 0;
 }
 
-int sgpr_profile_begin(void) { gemm_profile_begin(); return 0; }
-int sgpr_profile_end(double *out8)
+int sgpr_profile_begin(void) { return gemm_profile_begin(); }
+int sgpr_profile_end(double *out12)
 {
-    if (!out8) { set_error("null argument"); return SGPR_E_ARG; }
-    return gemm_profile_end(out8);
+    if (!out12) { set_error("null argument"); return SGPR_E_ARG; }
+    return gemm_profile_end(out12);
 }
 
 int sgpr_profile_launches(double *buf, int max_records) { return gemm_profile_launches(buf, max_records); }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_tile.h"
 
 namespace sgpr {
 
@@ -44,13 +45,11 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 //            lower triangle in 4x4 register tiles;
 //   inverse: the eight 16x16 diagonal blocks at once, then recursive doubling (16 -> 32 -> 64 -> 128):
 //            X21 = -X22 L21 X11 for every pair of a level on the matrix cores.
-__global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda, double *inv,
-                                                  int *dinfo, int goff, int mode,
-                                                  unsigned long long *stamps)
+__device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sInv /* PW * (PW + 1) */,
+                                          double *sRl /* PW: 1 / L11(j,j) of the current panel */, int nb,
+                                          double *A, size_t lda, double *inv, int *dinfo, int goff, int mode,
+                                          unsigned long long *stamps)
 {
-    __shared__ double s[LEAF * LLD];
-    __shared__ double sInv[PW * (PW + 1)];
-    __shared__ double sRl[PW];                      // 1 / L11(j,j) of the current panel
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // diagnostic phase clock (stamps == nullptr in production): cycles per phase, summed over panels
@@ -310,6 +309,16 @@ __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda,
         for (int i = 0; i < 8; ++i) stamps[i] = ph[i];
 }
 
+constexpr int LEAF_LDS = LEAF * LLD + PW * (PW + 1) + PW;   // doubles of LDS leaf_body needs
+
+__global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda, double *inv,
+                                                  int *dinfo, int goff, int mode,
+                                                  unsigned long long *stamps)
+{
+    __shared__ double s[LEAF_LDS];
+    leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), nb, A, lda, inv, dinfo, goff, mode, stamps);
+}
+
 // b(nb) := inv(L) b  or  inv(L)^T b   (inv: LEAF x LEAF lower, zero upper).
 // 1024 threads: row i = t & 127, k-slice = t >> 7 (8 slices of 16): sixteen independent loads per
 // thread instead of one 128-long dependent chain (25 us -> ~3 us per call).
@@ -434,6 +443,160 @@ __global__ __launch_bounds__(MV_T) void trsv_block_kernel(int n, const double *L
     for (int r = t; r < n; r += MV_T) b[r] = sx[r];
 }
 
+
+// ---- persistent panel kernel ------------------------------------------------------------------
+// One launch factors a whole block column ("panel") of the blocked right-looking driver: the
+// nb x nb diagonal block (W = nb / 128 leaf columns) and all rows below it (R strips of 128 rows,
+// the first W of them being the diagonal block's).  In round 1 every leaf column cost three dependent
+// launches (leaf, rows-below x inverse, fold into the remaining columns: 60 + 74 + 99 us) on the
+// stream the whole factorisation waits for; here the same tasks run inside ONE grid and hand their
+// results over through flags in global memory:
+//     strip c (its own workgroup):  ... -> leaf(c): factor + invert A(c,c) in LDS        -> I[c]
+//     strip r > c:  wait I[c];  X = A(r,c) inv(L_cc)^T  (a 128^3 product on the matrix cores)
+//                   diagonal strips (r < W) publish X = L(r,c)                           -> F[r][c]
+//                   wait F[c'][c];  A(r,c') -= X L(c',c)^T   for the panel's columns c' in (c, min(W-1, r)]
+//     strip c+1 goes straight from its column-c update to leaf(c+1): the chain the next panel step
+//     waits for is  leaf -> hand-off -> two 128^3 products -> leaf,  with no kernel boundary in it.
+// Workgroups 0..W-1 own the diagonal strips (one each), the others share the strips below round-robin.
+// Hand-off protocol (cdna_hip_programming.md, guideline 16): plain payload stores -> every storing
+// wave drains vmcnt -> workgroup barrier -> one lane: agent-scope release fence, drain, relaxed
+// agent-scope flag store; the consumer polls that word relaxed (one lane, s_sleep between polls),
+// then ONE agent-scope acquire, drain, workgroup barrier, plain loads.
+// Forward progress does not rely on co-residency of the grid: strip ownership follows the ARRIVAL
+// order of the workgroups (a ticket), so every flag a workgroup waits for is set by a workgroup that
+// started before it.  Every spin is bounded; a timeout is reported through *dinfo (PANEL_TIMEOUT).
+constexpr int PW_MAX = 8;                       // leaf columns per panel (nb <= 1024)
+constexpr int PFLAG_STRIDE = 2 + PW_MAX + PW_MAX * PW_MAX + 6;   // ints of flag state per panel (80)
+constexpr int PANEL_TIMEOUT = POTRF_HANDOFF_TIMEOUT;   // *dinfo value: a hand-off was never published
+constexpr int PANEL_G_MAX = 256;                // workgroups (each holds a whole CU: 133 KiB of LDS)
+
+struct PanelArgs {
+    double *P;        // panel origin: element (k0, k0) of the matrix
+    size_t lda;
+    int R, W, G;      // row strips (incl. the W diagonal ones), leaf columns, workgroups
+    double *inv;      // leaf inverses of this panel's W leaves (LEAF x LEAF each)
+    int *dinfo;
+    int goff;         // global index of the panel's first row / column (LAPACK info)
+    int *flags;       // PFLAG_STRIDE ints, zero on entry: [0] ticket, [2 + c] I[c], [2 + PW_MAX + r * PW_MAX + c] F[r][c]
+};
+
+typedef __attribute__((address_space(1))) int gint;
+
+__device__ __forceinline__ void panel_publish(int *flag)
+{
+    // every wave has drained its stores before the barrier; then one lane releases and signals
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store((gint *)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Wait until every flag in flags[idx[0..cnt)] is set.  Returns false (workgroup-uniform) on timeout.
+__device__ __forceinline__ bool panel_wait(int *flags, const int *idx, int cnt, int *dinfo, int *sh)
+{
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        for (int q = 0; q < cnt && ok; ++q) {
+            gint *f = (gint *)(flags + idx[q]);
+            unsigned spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (3u << 20)) { ok = 0; break; }    // ~ 3 s
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!ok) atomicCAS(dinfo, 0, PANEL_TIMEOUT);
+        *sh = ok;
+    }
+    __syncthreads();
+    const int ok = *sh;
+    __syncthreads();
+    return ok != 0;
+}
+
+// C (128 x 128) := beta C + alpha A B^T, k = 128, one workgroup of 256 threads, operands / result in
+// global memory (column-major panels: see gemm_tile.h)
+__device__ __forceinline__ void panel_product(double *smem, double alpha, const double *A, size_t lda,
+                                              const double *B, size_t ldb, double beta, double *C, size_t ldc)
+{
+    tile::GemmArgs ga{};
+    ga.m = LEAF; ga.n = LEAF; ga.k = LEAF;
+    ga.alpha = alpha; ga.beta = beta;
+    ga.A = A; ga.lda = lda; ga.B = B; ga.ldb = ldb; ga.C = C; ga.ldc = ldc;
+    ga.stamps = nullptr;
+    // the previous task's stores are visible to this workgroup, and its LDS reads are finished
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile::gemm_body_dma<LEAF, LEAF, 2>(ga, smem, 0, 0);
+}
+
+__global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
+{
+    __shared__ double s[LEAF_LDS];     // the leaf's 128 x 130 block; the products stage through its first 72 KiB
+    __shared__ int sh[2];
+    static_assert(2 * tile::BK * 2 * (LEAF + tile::PAD) <= LEAF_LDS, "product staging fits the leaf buffer");
+    const int tid = threadIdx.x;
+    if (tid == 0) sh[0] = atomicAdd(a.flags, 1);
+    __syncthreads();
+    const int g = sh[0];
+    __syncthreads();
+    const int W = a.W, R = a.R, G = a.G;
+    if (g >= G) return;
+    const int F0 = 2 + PW_MAX;
+    auto tileptr = [&](int r, int c) { return a.P + (size_t)r * LEAF + (size_t)c * LEAF * a.lda; };
+    // Strips of this workgroup: workgroups 0..W-1 own one diagonal strip each (rows g of the diagonal
+    // block, columns 0..g-1 to process, then their own leaf); the others share the strips below.
+    const bool diag = g < W;
+    const int nw = G - W;
+    const int r_first = diag ? g : W + (g - W), r_step = diag ? R : (nw > 0 ? nw : R);
+    const int ncol = diag ? g : W;
+    int idx[PW_MAX];
+    if (!(diag && g == 0)) {
+        for (int c = 0; c < ncol; ++c) {
+            bool have_inv = false, have_rows = false;
+            for (int r = r_first; r < R; r += r_step) {
+                if (!have_inv) {                       // inv(L_cc) published by strip c's workgroup
+                    idx[0] = 2 + c;
+                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+                    have_inv = true;
+                }
+                double *X = tileptr(r, c);
+                const int last = min(W - 1, r);        // columns c+1..last of this strip take the update
+                for (int t = 0; t <= last - c; ++t) {
+                    if (t == 1) {
+                        // X = L(r,c) is complete: a diagonal strip hands it to the strips below it
+                        if (diag) panel_publish(a.flags + F0 + r * PW_MAX + c);
+                        // ... and the update needs L(c',c) of the diagonal strips c' in (c, last], other than r
+                        if (!have_rows) {
+                            int cnt = 0;
+                            for (int cc = c + 1; cc <= last; ++cc)
+                                if (cc != r) idx[cnt++] = F0 + cc * PW_MAX + c;
+                            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1)) return;
+                            have_rows = true;
+                        }
+                    }
+                    const bool solve = t == 0;
+                    const double *B = solve ? a.inv + (size_t)c * LEAF * LEAF : tileptr(c + t, c);
+                    panel_product(s, solve ? 1.0 : -1.0, X, a.lda, B, solve ? (size_t)LEAF : a.lda, solve ? 0.0 : 1.0,
+                                  solve ? X : tileptr(r, c + t), a.lda);
+                }
+            }
+        }
+    }
+    if (diag) {
+        // this strip's diagonal tile has taken the updates of all earlier columns: factor + invert it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, tileptr(g, g), a.lda,
+                  a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr);
+        panel_publish(a.flags + 2 + g);
+    }
+}
+
 inline int split(int n)
 {
     // first part: a multiple of LEAF close to n/2 (>= LEAF, < n)
@@ -447,6 +610,7 @@ struct Ctx {
     int *dinfo;
     hipStream_t st;
     int la_max = 0;   // potrf_rec hands blocks of order <= la_max to the look-ahead driver (0: never)
+    int *flags = nullptr;   // hand-off flags of the panel kernel: PFLAG_STRIDE ints per leaf column, zeroed by potrf()
 };
 
 int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0);
@@ -496,7 +660,7 @@ int potrf_rec(int n, double *A, size_t lda, int off, const Ctx &c)
     }
     // mid-size blocks (also the halves a large recursive factorisation splits into): blocked
     // right-looking with the next panel on a side stream
-    if (n > 4 * LEAF && n <= c.la_max) return potrf_lookahead(n, A, lda, c, la_block(n), off);
+    if (n > 4 * LEAF && n <= c.la_max) return potrf_lookahead(n, A, lda, c, 0, off);
     const int n1 = split(n), n2 = n - n1;
     double *A21 = A + n1, *A22 = A + n1 + (size_t)n1 * lda;
     int rc = potrf_rec(n1, A, lda, off, c);
@@ -568,11 +732,16 @@ inline size_t inv_bytes(int n)
 {
     return (size_t)((n + LEAF - 1) / LEAF) * LEAF * LEAF * sizeof(double);
 }
+// flag block of the panel that starts at leaf column t: flags + t * PFLAG_STRIDE
+inline size_t flag_bytes(int n)
+{
+    return (((size_t)((n + LEAF - 1) / LEAF) * PFLAG_STRIDE * sizeof(int)) + 255) / 256 * 256;
+}
 
 
 }  // namespace
 
-size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + 256; }
+size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + flag_bytes(n) + 256; }
 
 namespace {
 
@@ -590,44 +759,138 @@ namespace {
 // loses 6 % of the chip and the tile map its 256-CU geometry).
 // The numbers are the same operations in a different order; the leaf workspace layout is shared with
 // the recursive driver, so the solves do not care which one produced L.
+// events of one look-ahead factorisation; destroyed on every exit path
+struct EventSet {
+    std::vector<hipEvent_t> ev;
+    int create(size_t count)
+    {
+        ev.assign(count, nullptr);
+        for (auto &e : ev) SGPR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return 0;
+    }
+    ~EventSet()
+    {
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+// whatever happens in between, the caller's stream waits for everything queued on the side stream
+struct StreamJoin {
+    hipStream_t side, caller;
+    hipEvent_t ev;
+    ~StreamJoin()
+    {
+        if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(caller, ev, 0) != hipSuccess)
+            (void)hipStreamSynchronize(side);
+        gemm_set_overlap(0);
+    }
+};
+
 int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0)
 {
     static hipStream_t side[64] = {};          // one side stream per device, created on first use
-    int dev = 0;
-    SGPR_HIP(hipGetDevice(&dev));
+    int dev = -1;
+    if (c.st) {
+        SGPR_HIP(hipStreamGetDevice(c.st, &dev));          // the device that owns the caller's stream
+    } else {
+        SGPR_HIP(hipGetDevice(&dev));                      // the null stream belongs to the current device
+    }
     if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
     {
         static std::mutex mu;                       // two fit handles may factor for the first time at once
         std::lock_guard<std::mutex> lock(mu);
         if (!side[dev]) {
-            int lo = 0, hi = 0;
-            SGPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            SGPR_HIP(hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi));
+            int cur = -1, lo = 0, hi = 0;
+            SGPR_HIP(hipGetDevice(&cur));
+            if (cur != dev) SGPR_HIP(hipSetDevice(dev));
+            hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi);
+            if (cur != dev) (void)hipSetDevice(cur);
+            SGPR_HIP(e);
         }
     }
     const hipStream_t sp = side[dev];
-    const int nblk = (n + nb - 1) / nb;
-    std::vector<hipEvent_t> ev(2 * (size_t)nblk + 1);
-    for (auto &e : ev) SGPR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    auto cleanup = [&](int rc) {
-        for (auto &e : ev) (void)hipEventDestroy(e);
-        return rc;
-    };
+    // Panel kernel usable?  (The multi-launch panels below remain for shapes it does not take and for A/B runs.)
+    static const int pmode = [] {
+        const char *e = getenv("SGPR_LA_PANEL");
+        return !e ? 3 : (e[0] == 'l' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'c' ? 0 : 3)));
+    }();
+    const bool fused_cap = pmode == 3 && c.flags && n % LEAF == 0 && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0) &&
+                           off0 % LEAF == 0;
+    // Block schedule.  nb > 0: uniform width (the caller's choice).  nb == 0: widths follow the order of
+    // what is left: wide blocks (k = 1024 products run at ~61 TFLOP/s, k = 512 at ~52) while the trailing
+    // update is what each step waits for, narrower ones once the chain of leaves is (the chain costs the
+    // same per column at any width, and a narrow step loses less to its own update of block column k+1).
+    std::vector<int> starts;
+    {
+        static const int t1 = [] { const char *e = getenv("SGPR_LA_T1"); return e ? atoi(e) : 9216; }();
+        static const int t2 = [] { const char *e = getenv("SGPR_LA_T2"); return e ? atoi(e) : 2048; }();
+        for (int pos = 0; pos < n;) {
+            starts.push_back(pos);
+            const int rem = n - pos;
+            int w = nb > 0 ? nb : (rem > t1 ? 1024 : (rem > t2 ? 512 : 256));
+            if (nb == 0 && !fused_cap) w = la_block(n);
+            pos += std::min(w, rem);
+        }
+        starts.push_back(n);
+    }
+    const int nblk = (int)starts.size() - 1;
+    int wmax = 0;
+    for (int k = 0; k < nblk; ++k) wmax = std::max(wmax, starts[k + 1] - starts[k]);
+    EventSet es;
+    {
+        const int rc0 = es.create(3 * (size_t)nblk + 3);
+        if (rc0) return rc0;
+    }
+    std::vector<hipEvent_t> &ev = es.ev;
     const hipStream_t su = c.st;
-    Ctx cp{c.inv, c.dinfo, sp, 0};
-    // Panel k = diagonal block + everything below it, factored leaf column by leaf column over its
-    // full height: factor the 128 x 128 diagonal leaf, multiply the rows below by its inverse, fold
-    // that column into the panel's remaining columns (one lower-trapezoid product, k = 128).
-    // 3 launches per leaf column (11 for nb = 512) where factoring the diagonal block recursively
-    // and then solving the rows below takes 19 -- on this stream every launch is a link of the
-    // serial chain the whole factorisation waits for.  SGPR_LA_PANEL=l folds left-looking instead
-    // (column j collects columns 0..j-1 in one product of growing k: n = 16384 39.4 vs 37.9 ms),
-    // =r is the recursive form (43.9 -> 48.7 ms before the epilogue fix).
-    static const int pmode = [] { const char *e = getenv("SGPR_LA_PANEL"); return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'r' ? 2 : 0)); }();
-    const bool left = pmode != 2, right_in = pmode == 0;
+    Ctx cp{c.inv, c.dinfo, sp, 0, c.flags};
+    // Panel k = diagonal block + everything below it.  Default: ONE launch of the persistent panel kernel
+    // (above).  The multi-launch forms: SGPR_LA_PANEL=c "column": leaf column by leaf column, factor the
+    // 128 x 128 leaf, multiply the rows below by its inverse, fold that column into the panel's remaining
+    // columns (3 launches per leaf column; round 1's default); =l folds left-looking instead; =r factors
+    // the diagonal block recursively and then solves the rows below (19 launches for nb = 512).
+    const bool fused_ok = fused_cap && wmax % LEAF == 0 && wmax / LEAF <= PW_MAX;
+    const bool left = pmode != 2, right_in = pmode == 0 || pmode == 3;
     auto panel = [&](int k) -> int {   // on the P stream
-        const int k0 = k * nb, w = std::min(nb, n - k0), rows = n - k0, below = rows - w;
+        const int k0 = starts[k], w = starts[k + 1] - k0, rows = n - k0, below = rows - w;
         double *Akk = A + k0 + (size_t)k0 * lda;
+        if (fused_ok) {
+            PanelArgs pa;
+            pa.P = Akk; pa.lda = lda;
+            pa.R = rows / LEAF; pa.W = w / LEAF;
+            const int nbelow = pa.R - pa.W;
+            // While the step is bound by the trailing update running beside the panel (not by the chain of
+            // leaves), the kernel takes the diagonal block only -- W workgroups, the chain -- and the rows
+            // below are solved by the grid-wide MFMA kernel afterwards: inside the persistent kernel a strip
+            // below costs ~W (W + 3) / 2 products of 128^3, each on a CU of its own at 20 us alone and 2-3x
+            // that beside a bandwidth-hungry update (a 1024-wide panel over 14336 rows: 3.1 - 5.7 ms).
+            // Once the chain is what the step waits for, every strip gets its own workgroup: one launch, the
+            // strips below finish ~20 us after the last leaf.
+            const double m_u2 = (double)(rows + w);                    // order of the update running beside
+            const double u2_us = k > 0 ? m_u2 * m_u2 * (starts[k] - starts[k - 1]) / 55e6 : 0.0;
+            const bool split = nbelow > 0 && k > 0 && u2_us > 3.0 * (125.0 * pa.W + 100.0);
+            if (split) {
+                pa.R = pa.W;
+                pa.G = pa.W;
+            } else {
+                // strips below per workgroup: as many as still finish under the update (each workgroup holds
+                // a whole CU, 133 KiB of LDS, that the update loses); one each once the chain is the limit
+                const double strip_us = 30.0 * (pa.W * (pa.W + 1) / 2 + pa.W), chain_us = 125.0 * pa.W;
+                int per_wg = (int)((0.7 * u2_us - 0.5 * chain_us) / strip_us);
+                per_wg = std::max(1, std::min(per_wg, 4));
+                const int nwg = std::min((nbelow + per_wg - 1) / per_wg, PANEL_G_MAX - pa.W);
+                pa.G = pa.W + (nbelow > 0 ? std::max(1, nwg) : 0);
+            }
+            const int t0 = (off0 + k0) / LEAF;
+            pa.inv = cp.inv + (size_t)t0 * LEAF * LEAF;
+            pa.dinfo = cp.dinfo; pa.goff = off0 + k0;
+            pa.flags = c.flags + (size_t)t0 * PFLAG_STRIDE;
+            hipLaunchKernelGGL(panel_kernel, dim3(pa.G), dim3(LT), 0, sp, pa);
+            SGPR_CHECK_LAUNCH();
+            if (split) return trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
+            return 0;
+        }
         if (!left) {
             int rc = potrf_rec(w, Akk, lda, off0 + k0, cp);
             if (rc) return rc;
@@ -657,30 +920,40 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
     int rc;
     SGPR_HIP(hipEventRecord(ev[2 * nblk], su));                // the side stream joins the caller's stream ...
     SGPR_HIP(hipStreamWaitEvent(sp, ev[2 * nblk], 0));
-    if ((rc = panel(0))) return cleanup(rc);
+    StreamJoin join{sp, su, ev[2 * nblk + 1]};                 // ... and leaves it again on every exit path
+    gemm_set_overlap(1);                                       // launches below share the device (profile records)
+    // Schedule (P = high-priority side stream, U = the caller's stream):
+    //   P:  panel(0);  for k:  [after U2(k-1)]  U1(k) = update of block column k+1 by panel k;  panel(k+1)
+    //   U:             for k:  [after panel(k)]  U2(k) = update of everything right of block column k+1
+    // U1 is a short launch (m x nb x nb) that fills half the chip at best; on the P stream it runs beside
+    // the start of U2(k) instead of in front of it, so the U stream does big updates back to back.
+    if ((rc = panel(0))) return rc;
     SGPR_HIP(hipEventRecord(ev[0], sp));
     for (int k = 0; k < nblk; ++k) {
-        const int k0 = k * nb, w = std::min(nb, n - k0);
+        const int k0 = starts[k], w = starts[k + 1] - k0;
         const int k1 = k0 + w;                                 // first row / column of block column k+1
-        SGPR_HIP(hipStreamWaitEvent(su, ev[2 * k], 0));        // panel k is ready
         if (k1 >= n) break;
-        const int w1 = std::min(nb, n - k1), k2 = k1 + w1;
+        const int w1 = starts[k + 2] - k1, k2 = k1 + w1;
         const double *Lk = A + (size_t)k0 * lda;               // panel k: columns k0..k0+w
-        // U1: block column k+1 (rows k1.., columns k1..k2)
-        if ((rc = gemm_nt(n - k1, w1, w, -1.0, Lk + k1, lda, Lk + k1, lda, 1.0, A + k1 + (size_t)k1 * lda, lda, 1, 0, su)))
-            return cleanup(rc);
-        SGPR_HIP(hipEventRecord(ev[2 * k + 1], su));
-        SGPR_HIP(hipStreamWaitEvent(sp, ev[2 * k + 1], 0));
-        if ((rc = panel(k + 1))) return cleanup(rc);
+        // U1 on P: block column k+1 (rows k1.., columns k1..k2); U2(k-1) has touched it before
+        if (k > 0) SGPR_HIP(hipStreamWaitEvent(sp, ev[2 * (k - 1) + 1], 0));
+        if ((rc = gemm_nt(n - k1, w1, w, -1.0, Lk + k1, lda, Lk + k1, lda, 1.0, A + k1 + (size_t)k1 * lda, lda, 1, 0, sp)))
+            return rc;
+        // Once the steps are bound by the chain panel -> U1 -> panel and no longer by U2, U2(k) starts only
+        // when U1(k) has run: beside a freshly started U2 the short U1 waits for CUs and takes 2-3x longer.
+        const double u2_us = (double)(n - k2) * (n - k2) * w / 55e6;
+        const bool chain_bound = u2_us < 1.5 * (125.0 * (w1 / LEAF) + 100.0);
+        if (chain_bound) SGPR_HIP(hipEventRecord(ev[2 * nblk + 2 + k], sp));
+        if ((rc = panel(k + 1))) return rc;
         SGPR_HIP(hipEventRecord(ev[2 * (k + 1)], sp));
-        // U2: the rest of the trailing matrix (rows / columns k2..)
+        // U2 on U: the rest of the trailing matrix (rows / columns k2..), as soon as panel k is there
+        SGPR_HIP(hipStreamWaitEvent(su, chain_bound ? ev[2 * nblk + 2 + k] : ev[2 * k], 0));
         if (k2 < n &&
             (rc = gemm_nt(n - k2, n - k2, w, -1.0, Lk + k2, lda, Lk + k2, lda, 1.0, A + k2 + (size_t)k2 * lda, lda, 1, 0, su)))
-            return cleanup(rc);
+            return rc;
+        SGPR_HIP(hipEventRecord(ev[2 * k + 1], su));
     }
-    SGPR_HIP(hipEventRecord(ev[2 * nblk], sp));                // ... and leaves it again
-    SGPR_HIP(hipStreamWaitEvent(su, ev[2 * nblk], 0));
-    return cleanup(0);
+    return 0;
 }
 
 }  // namespace
@@ -691,13 +964,16 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     if (lwork < potrf_workspace(n)) { set_error("potrf: workspace too small"); return SGPR_E_ARG; }
     SGPR_HIP(hipMemsetAsync(dinfo, 0, sizeof(int), st));
     if (n == 0) return 0;
+    // hand-off flags of the panel kernel (behind the leaf inverses): zero before every factorisation
+    int *flags = reinterpret_cast<int *>(static_cast<char *>(work) + inv_bytes(n));
+    SGPR_HIP(hipMemsetAsync(flags, 0, flag_bytes(n), st));
     // blocked + look-ahead for mid sizes and for the mid-size blocks of a large recursive
     // factorisation, recursive above (measured crossover; SGPR_POTRF=rec|la overrides)
     static const int mode = [] { const char *e = getenv("SGPR_POTRF"); return !e ? 0 : (e[0] == 'r' ? 1 : 2); }();
     static const int nb_env = [] { const char *e = getenv("SGPR_POTRF_NB"); return e ? atoi(e) : 0; }();
-    Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : 57344};
+    Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : 57344, flags};
     if (mode == 2 || (nb_env > 0 && mode == 0 && n > 4 * LEAF && n <= c.la_max))
-        return potrf_lookahead(n, A, lda, c, nb_env > 0 ? nb_env : la_block(n), 0);
+        return potrf_lookahead(n, A, lda, c, nb_env > 0 ? nb_env : 0, 0);
     return potrf_rec(n, A, lda, 0, c);
 }
 
@@ -709,10 +985,30 @@ int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, c
     return trsm_rec(m, n, L, ldl, B, ldb, 0, c);
 }
 
+// The strip kernels (trsv.hip) take over above one block of the single-workgroup kernel; their ticket /
+// progress words live in the flag area behind the leaf inverses (idle once the factor exists).
+// SGPR_TRSV=rec keeps the recursive GEMV form (A/B runs).
+static bool use_strips(int n, const double *L, size_t ldl)
+{
+    static const bool off = [] { const char *e = getenv("SGPR_TRSV"); return e && e[0] == 'r'; }();
+    return !off && n > TRSV_BLOCK && trsv_strips_ok(n, L, ldl);
+}
+static int *solve_state(int n, const void *work)
+{
+    return reinterpret_cast<int *>(const_cast<char *>(static_cast<const char *>(work)) + inv_bytes(n));
+}
+
 int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st)
 {
     if (n <= 0) return 0;
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
+    if (use_strips(n, L, ldl)) {
+        int *state = solve_state(n, work);
+        SGPR_HIP(hipMemsetAsync(state, 0, 8 * sizeof(int), st));
+        int rc = trsv_strips(n, L, ldl, c.inv, b, 0, state, st);
+        if (rc) return rc;
+        return trsv_strips(n, L, ldl, c.inv, b, 1, state + 4, st);
+    }
     int rc = trsv_n_rec(n, L, ldl, b, 0, c);
     if (rc) return rc;
     return trsv_t_rec(n, L, ldl, b, 0, c);
@@ -743,6 +1039,11 @@ int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int tr
 {
     if (n <= 0) return 0;
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
+    if (use_strips(n, L, ldl)) {
+        int *state = solve_state(n, work);
+        SGPR_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int), st));
+        return trsv_strips(n, L, ldl, c.inv, b, trans, state, st);
+    }
     return trans ? trsv_t_rec(n, L, ldl, b, 0, c) : trsv_n_rec(n, L, ldl, b, 0, c);
 }
 

@@ -73,14 +73,25 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
                hipStream_t st);
 int gemm_nn(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
             double beta, double *C, size_t ldc, hipStream_t st);
-void gemm_profile_begin();
-void gemm_set_stamps(unsigned long long *dev_buf);
-void gemm_set_debug(int bits);
-int gemm_profile_end(double *out8);
+int gemm_profile_begin();
+int gemm_profile_end(double *out12);
 int gemm_profile_launches(double *buf, int max_records);
+void gemm_set_overlap(int on);   // look-ahead driver: launches from here on share the device (thread-local)
+// diagnostics (libsympgpr_probe.so only): per-workgroup clock stamps, tile-shape / staging switches
+int gemm_nt_diag(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
+                 double beta, double *C, size_t ldc, int lower, unsigned long long *stamps, int dbg, hipStream_t st);
 
 // ---- chol.hip : leaf factor / leaf inverse / recursion / solves
 constexpr int LEAF = 128;  // order of the diagonal block factored in LDS by one workgroup
+// value left in *dinfo when a hand-off inside the persistent panel kernel timed out (a bug or a
+// device problem, never a property of the matrix); info_status() turns it into SGPR_E_HIP
+constexpr int POTRF_HANDOFF_TIMEOUT = -1000001;
+inline int info_status(int info)
+{
+    if (info >= 0) return info;
+    set_error(info == POTRF_HANDOFF_TIMEOUT ? "potrf: a hand-off inside the panel kernel timed out" : "potrf: internal error");
+    return SGPR_E_HIP;
+}
 size_t potrf_workspace(int n);
 int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st);
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
@@ -92,6 +103,11 @@ int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, s
 int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st);
 int leaf_probe(double *A, size_t lda, double *inv, int *dinfo, unsigned long long *stamps, hipStream_t st);
 int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st);
+
+// ---- trsv.hip : one-right-hand-side triangular solve as one launch (strips + progress counter)
+bool trsv_strips_ok(int n, const double *L, size_t ldl);
+int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state /* 4 ints, zero */,
+                hipStream_t st);
 
 // ---- blas_small.hip
 int zero_strict_upper(int n, double *A, size_t lda, hipStream_t st);

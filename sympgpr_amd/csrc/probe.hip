@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "common.h"
+#include "../../include/sympgpr_probe.h"
 
 namespace sgpr {
 namespace {
@@ -150,7 +151,8 @@ extern "C" int sgpr_probe_hbm_write(size_t bytes, int reps, double *gbs)
 // Diagnostic: run one C -= A B^T (m x n x k, synthetic operands) with per-workgroup stamps and
 // report [0] TFLOP/s (event), [1] median shader cycles a workgroup spent in its k-loop,
 // [2] median shader clock (GHz) during it, [3] k-steps (of 16) per workgroup.
-extern "C" int sgpr_probe_gemm_debug(int bits) { gemm_set_debug(bits); return 0; }
+static thread_local int t_probe_dbg = 0;   // switches of the NEXT sgpr_probe_gemm calls on this thread only
+extern "C" int sgpr_probe_gemm_debug(int bits) { t_probe_dbg = bits; return 0; }
 
 extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
 {
@@ -181,13 +183,11 @@ extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
     hipEvent_t a, b;
     SGPR_HIP(hipEventCreate(&a));
     SGPR_HIP(hipEventCreate(&b));
-    int rc = gemm_nt(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, 0, nullptr);  // warm
+    int rc = gemm_nt_diag(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, nullptr, t_probe_dbg, nullptr);  // warm
     if (rc) return rc;
-    gemm_set_stamps(st);
     SGPR_HIP(hipEventRecord(a, nullptr));
-    rc = gemm_nt(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, 0, nullptr);
+    rc = gemm_nt_diag(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, st, t_probe_dbg, nullptr);
     SGPR_HIP(hipEventRecord(b, nullptr));
-    gemm_set_stamps(nullptr);
     if (rc) return rc;
     SGPR_HIP(hipEventSynchronize(b));
     float ms = 0.f;

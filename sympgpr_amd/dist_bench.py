@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 
 
-def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_pairs=None):
+def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_pairs=None, cpu_baseline=None):
     from .dist import DistFit, HipOps, grid_shape
     dev = torch.device("cuda", local_rank)
     ops = HipOps(dev)

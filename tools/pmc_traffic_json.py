@@ -8,7 +8,10 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950: cali
 which reads L exactly once and reports half of it)."""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from collections import defaultdict
 
 fetch_csv, write_csv, launches_json, n_pts = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
@@ -30,9 +33,10 @@ ft, fc = sums(fetch_csv, "FETCH_SIZE")
 wt, wc = sums(write_csv, "WRITE_SIZE")
 la = json.load(open(launches_json))
 n = 2 * n_pts
-out = {"config": {"n_pts": n_pts, "order_n": n, "family": "A", "triangle": "full"},
+out = {"config": {"n_pts": n_pts, "order_n": n, "family": "A", "triangle": "full", "pairs_per_point": 1},
+       "code_hash": __import__("bench").kernel_code_hash(),
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) of bench.py --steps 1 "
-                 "--warmup 0 --cpu-sample 0 --no-launch-events; FETCH_SIZE doubled per the gfx950 note, calibrated on "
+                 "--warmup 0 --cpu-sample 0 --no-launch-events (bench.py itself skips its event pass under the profiler); FETCH_SIZE doubled per the gfx950 note, calibrated on "
                  "gemv_n; traffic = (2 FETCH + WRITE) KiB * 1024 / launches"}
 for key, name in (("gemm_nt_kernel<256, 128>", "gemm_nt_kernel<256, 128>"), ("gram_pairs_kernel<0, false, 0>", "gram_pairs_kernel")):
     f, w, c = ft.get(key, 0.0), wt.get(key, 0.0), max(fc.get(key, 0), 1)

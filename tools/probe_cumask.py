@@ -6,7 +6,7 @@ lib = L.load_library()
 def run(words, nb=512):
     m = (C.c_uint * len(words))(*words)
     out = (C.c_int * (2 * nb))()
-    L.check(lib.sgpr_probe_cumask(m, len(words), nb, out))
+    L.check(L.load_probe_library().sgpr_probe_cumask(m, len(words), nb, out))
     a = np.array(out[:]).reshape(nb, 2)
     xcc = a[:, 0]; hw = a[:, 1]
     cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7

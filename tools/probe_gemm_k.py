@@ -8,7 +8,7 @@ lib = L.load_library()
 o = np.zeros(4)
 ks, ts = [], []
 for k in (128, 256, 512, 1024, 2048, 4096, 8192):
-    L.check(lib.sgpr_probe_gemm(16384, 16384, k, 0, L.dptr(o)))
+    L.check(L.load_probe_library().sgpr_probe_gemm(16384, 16384, k, 0, L.dptr(o)))
     t_tile = 2.0 * 256 * 128 * k / (o[0] * 1e12 / 256) * 1e6      # us per tile (one tile per CU at a time)
     loop_us = o[1] / (o[2] * 1e3) if o[2] > 0 else float("nan")
     ks.append(k); ts.append(t_tile)

@@ -3,7 +3,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from sympgpr_amd import _lib as L
 lib = L.load_library()
 o = np.zeros(8)
-L.check(lib.sgpr_probe_leaf(L.dptr(o)))
+L.check(L.load_probe_library().sgpr_probe_leaf(L.dptr(o)))
 names = ["load", "diag(A)", "panel(B)", "update(C)", "writeback", "inv diag", "inv rows", "tail store"]
 tot = o.sum()
 for n, v in zip(names, o):

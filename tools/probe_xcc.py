@@ -5,7 +5,7 @@ from sympgpr_amd import _lib as L
 lib = L.load_library()
 n = 2048
 out = (C.c_int * n)()
-L.check(lib.sgpr_probe_xcc(n, out))
+L.check(L.load_probe_library().sgpr_probe_xcc(n, out))
 x = np.array(out[:])
 print("first 32:", x[:32])
 print("ids seen:", sorted(set(x.tolist())))
