@@ -178,6 +178,20 @@ int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double 
 int sgpr_fit_device_ptrs(sgpr_fit_t f, void **dA, size_t *lda, void **dalpha);
 int sgpr_fit_destroy(sgpr_fit_t f);
 
+/* ---- many small independent fits in ONE launch ----------------------------------------------
+ * The reference's only batch axis: `nphmap` independent GP pairs (one per toroidal section) and the
+ * CMA-ES populations that evaluate nll_chol for many hyper-parameter vectors
+ * (python/05_tokamak/Split_SympGPR/main.py:36-41,63-66,96-112), at matrix orders 40 ... 160.
+ * Problem b = 0..nbatch-1: the body of nll_chol (python/functions/func.py:189-196; with SGPR_FIT_REG
+ * of nll_chol_reg, :180-187) on points x[b*n_pts ..], y[b*n_pts ..], targets z[b*n ..], hyper-parameters
+ * hyp[b*nhyp ..], noise |sig2n[b]|;  n = 2 n_pts (n_pts with SGPR_FIT_REG) <= sgpr_fit_batch_max_order().
+ * Outputs (host): alpha (nbatch x n, may be NULL), nll (nbatch), info (nbatch; 0 or the LAPACK-style
+ * index of the first non-positive pivot of that problem -- the call itself still returns 0). */
+int sgpr_fit_batch_max_order(void);
+int sgpr_fit_batch(int family, int nbatch, int n_pts, const double *x, const double *y, const double *z,
+                   const double *hyp, int nhyp, const double *sig2n, unsigned flags, double *alpha,
+                   double *nll, int *info);
+
 /* ---- device-pointer primitives (the tiles a distributed driver composes) ------------------ */
 
 /* Pair-tile Gram build.  For pair rows i = 0..mi-1 (row point b = (xb[i], yb[i])) and pair

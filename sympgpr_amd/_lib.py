@@ -97,6 +97,9 @@ SIGNATURES = {
     "sgpr_applymap_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
                                      C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "sgpr_fit_batch_max_order": (C.c_int, []),
+    "sgpr_fit_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_uint, _dp, _dp,
+                                 C.POINTER(C.c_int)]),
 }
 
 # include/sympgpr_probe.h: measurement aids in their own library (never loaded by a product path)

@@ -801,6 +801,19 @@ int sgpr_fit_device_ptrs(sgpr_fit_t f, void **dA, size_t *lda, void **dalpha)
     return 0;
 }
 
+/* ---- many small fits in one launch ------------------------------------------------------- */
+
+int sgpr_fit_batch_max_order(void) { return fit_batch_max_order(); }
+
+int sgpr_fit_batch(int family, int nbatch, int n_pts, const double *x, const double *y, const double *z,
+                   const double *hyp, int nhyp, const double *sig2n, unsigned flags, double *alpha, double *nll,
+                   int *info)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return fit_batch(family, nbatch, n_pts, x, y, z, hyp, nhyp, sig2n, flags, alpha, nll, info);
+}
+
 /* ---- device-pointer primitives ---------------------------------------------------------- */
 
 int sgpr_gram_pairs_dev(int family, int mi, int mj, const double *xb, const double *yb,

@@ -20,296 +20,14 @@
 
 #include "common.h"
 #include "gemm_tile.h"
+#include "leaf.h"
 
 namespace sgpr {
 
 namespace {
 
-constexpr int LT = 256;            // threads of the leaf kernel
-constexpr int LLD = LEAF + 2;      // LDS leading dimension: even (16-B aligned column pairs), 4*LLD mod 64 banks = 8
-constexpr int PW = 16;             // panel width inside the leaf
+using namespace leaf;
 
-enum { LEAF_FACTOR = 0, LEAF_INVERT_ONLY = 1 };
-
-typedef double double2_t __attribute__((ext_vector_type(2)));
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// A (nb x nb, lower, global) -> L in place (mode FACTOR) and inv(L) -> inv (LEAF x LEAF,
-// ld LEAF, zero-filled outside the nb x nb lower triangle).
-//
-// One workgroup, the whole block in LDS (128 x 130 fp64 = 130 KiB), padded to 128 with an
-// identity so every loop bound is a compile-time constant.  Both phases work on 16-column
-// panels (8 panel steps, 3 barriers each) instead of one barrier-separated step per column:
-//   factor : 16x16 diagonal block by one wave (row per lane, pivots/columns via shuffles) ->
-//            panel rows solved one per thread against it -> rank-16 update of the trailing
-//            lower triangle in 4x4 register tiles;
-//   inverse: the eight 16x16 diagonal blocks at once, then recursive doubling (16 -> 32 -> 64 -> 128):
-//            X21 = -X22 L21 X11 for every pair of a level on the matrix cores.
-__device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sInv /* PW * (PW + 1) */,
-                                          double *sRl /* PW: 1 / L11(j,j) of the current panel */, int nb,
-                                          double *A, size_t lda, double *inv, int *dinfo, int goff, int mode,
-                                          unsigned long long *stamps)
-{
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    // diagnostic phase clock (stamps == nullptr in production): cycles per phase, summed over panels
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0;
-    auto mark = [&](int i) {
-        if (stamps) {
-            const unsigned long long t = __builtin_amdgcn_s_memtime();
-            ph[i] += t - tprev;
-            tprev = t;
-        }
-    };
-
-    if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
-        // full leaf: 32 independent 16-B loads per thread (the whole square is read, the strict
-        // upper triangle -- whatever it holds -- is replaced by zeros on the way into LDS)
-#pragma unroll 8
-        for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
-            const int idx = it * LT + tid;
-            const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
-            const double2_t v = *reinterpret_cast<const double2_t *>(A + (size_t)i + (size_t)c * lda);
-            s[c * LLD + i] = (i >= c) ? v.x : 0.0;
-            s[c * LLD + i + 1] = (i + 1 >= c) ? v.y : 0.0;
-        }
-    } else {
-        for (int idx = tid; idx < LEAF * LEAF; idx += LT) {
-            const int i = idx % LEAF, c = idx / LEAF;
-            double v = (i == c) ? 1.0 : 0.0;               // identity padding beyond nb
-            if (i < nb && c < nb) v = (i >= c) ? A[(size_t)i + (size_t)c * lda] : 0.0;
-            s[c * LLD + i] = v;
-        }
-    }
-    __syncthreads();
-    mark(0);
-
-    if (mode == LEAF_FACTOR) {
-        const int wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-        // (A) 16x16 diagonal block at c0, one wave: lane r holds row r in registers; the pivot of
-        // column j comes from lane j by v_readlane, 1/sqrt by the hardware estimate + two Newton
-        // steps, the scaled column is published through a 16-double LDS strip and read back as
-        // broadcasts (15 independent reads instead of a chain of dependent cross-lane shuffles).
-        auto diag_factor = [&](int c0) {
-            double a[PW];
-#pragma unroll
-            for (int c = 0; c < PW; ++c)
-                a[c] = (lane < PW && c <= lane) ? s[(c0 + c) * LLD + c0 + lane] : 0.0;
-            bool bad = false;
-            int badj = 0;
-            auto pivot = [&](double v, int j, double &d, double &rl) {   // d = v on lane j; rl = 1/sqrt(d)
-                const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), j);
-                const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), j);
-                d = __hiloint2double((int)hi, (int)lo);
-                rl = __builtin_amdgcn_rsq(d);
-                rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
-                rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
-            };
-            double d, rl;
-            pivot(a[0], 0, d, rl);
-#pragma unroll
-            for (int j = 0; j < PW; ++j) {
-                if (!(d > 0.0) && !bad) { bad = true; badj = j; }
-                a[j] = (lane == j) ? d * rl : a[j] * rl;
-                if (lane < PW) sInv[1 + lane] = a[j];
-                if (lane == j) sRl[j] = rl;
-                // the next pivot needs only lane j+1's own values (a[j+1] - a[j]^2): its 1/sqrt chain
-                // runs while column j travels through LDS
-                double dn = 0.0, rn = 0.0;
-                if (j + 1 < PW) pivot(__builtin_fma(-a[j], a[j], a[j + 1]), j + 1, dn, rn);
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int c = j + 1; c < PW; ++c) a[c] = __builtin_fma(-a[j], sInv[1 + c], a[c]);
-                __builtin_amdgcn_wave_barrier();
-                d = dn;
-                rl = rn;
-            }
-            if (bad && lane == 0 && *dinfo == 0) *dinfo = goff + c0 + badj + 1;
-            if (lane < PW) {
-#pragma unroll
-                for (int c = 0; c < PW; ++c)
-                    if (c <= lane) s[(c0 + c) * LLD + c0 + lane] = a[c];
-            }
-        };
-        // (C) one 16x16 tile of the trailing update on the matrix cores: k = 16 = four
-        // v_mfma_f64_16x16x4_f64; both operands are "row contiguous, k strided" reads of the
-        // panel columns (A: lane&15 = i, B: lane&15 = j, lane>>4 = k).
-        auto update_tile = [&](int c0, int i0, int j0) {
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < PW / 4; ++kk) {
-                const double *col = s + (c0 + 4 * kk + l4) * LLD;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(col[i0 + l15], col[j0 + l15], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[(j0 + l15) * LLD + i0 + 4 * r + l4] -= acc[r];  // D(i,j): j = lane&15, i = 4r + lane>>4
-        };
-
-        if (wave == 0) diag_factor(0);
-        __syncthreads();
-        mark(1);
-        for (int c0 = 0; c0 < LEAF - PW; c0 += PW) {
-            const int r0 = c0 + PW;
-            const int rem = LEAF - r0;
-            // ---- (B) panel rows: r := r L11^-T, one row per thread
-            if (tid < rem) {
-                const int i = r0 + tid;
-                double r[PW];
-#pragma unroll
-                for (int c = 0; c < PW; ++c) r[c] = s[(c0 + c) * LLD + i];
-#pragma unroll
-                for (int j = 0; j < PW; ++j) {
-                    double acc = r[j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) acc = __builtin_fma(-r[k], s[(c0 + k) * LLD + c0 + j], acc);
-                    r[j] = acc * sRl[j];
-                }
-#pragma unroll
-                for (int c = 0; c < PW; ++c) s[(c0 + c) * LLD + i] = r[c];
-            }
-            __syncthreads();
-            mark(2);
-            // ---- (C) trailing update, with the NEXT diagonal block factored underneath it: wave 0
-            // updates tile (0,0) first and goes straight on to (A) of the next panel while waves
-            // 1-3 update the other tiles.
-            const int nt = rem / 16;
-            const int ntile = nt * (nt + 1) / 2;
-            if (wave == 0) {
-                update_tile(c0, r0, r0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                diag_factor(r0);
-            } else {
-                for (int idx = wave; idx < ntile; idx += LT / 64 - 1) {
-                    int ti = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                    while (ti * (ti + 1) / 2 > idx) --ti;
-                    while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
-                    const int tj = idx - ti * (ti + 1) / 2;
-                    update_tile(c0, r0 + 16 * ti, r0 + 16 * tj);
-                }
-            }
-            __syncthreads();
-            mark(3);
-        }
-        if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
-#pragma unroll 8
-            for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
-                const int idx = it * LT + tid;
-                const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
-                double *dst = A + (size_t)i + (size_t)c * lda;
-                if (i >= c) *reinterpret_cast<double2_t *>(dst) = double2_t{s[c * LLD + i], s[c * LLD + i + 1]};
-                else if (i + 1 >= c) dst[1] = s[c * LLD + i + 1];
-            }
-        } else {
-            for (int idx = tid; idx < nb * nb; idx += LT) {
-                const int i = idx % nb, c = idx / nb;
-                if (i >= c) A[(size_t)i + (size_t)c * lda] = s[c * LLD + i];
-            }
-        }
-        __syncthreads();
-        mark(4);
-    }
-
-    // ---- inverse (LAPACK dtrtri order, last panel first); only the lower triangle of s is read.
-    // (I0) all eight 16x16 diagonal blocks are inverted at once, in place: 128 threads, one column
-    //      of one block each (x = solve L11 x = e_c), values held in registers across the barrier.
-    {
-        const int blk = tid >> 4, c = tid & 15, d0 = blk * PW;
-        double x[PW];
-        if (tid < 128) {
-#pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                double acc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; ++k) acc = __builtin_fma(-s[(d0 + k) * LLD + d0 + i], x[k], acc);
-                x[i] = acc / s[(d0 + i) * LLD + d0 + i];
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-#pragma unroll
-            for (int i = 0; i < PW; ++i)
-                if (i >= c) s[(d0 + c) * LLD + d0 + i] = x[i];
-        }
-        __syncthreads();
-    }
-    mark(5);
-    // (I1) recursive doubling: with the diagonal blocks of size b inverted, the blocks of size 2b follow
-    //      from X21 = -X22 L21 X11 for every pair at once -- three levels (b = 16, 32, 64), two small
-    //      matrix products each, instead of seven dependent panel steps (12.4 -> ~6 us).  The product
-    //      T = X22 L21 is parked in the strictly upper corner of s (rows 0..63, columns 64..127),
-    //      which nothing reads: the write-back below masks the upper triangle.
-    {
-        const int wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-        double *const scr = s + (LEAF / 2) * LLD;                 // scr[c * LLD + r], r < 64, c < 64
-        for (int b = PW; b < LEAF; b *= 2) {
-            const int tb = b / 16, per = tb * tb, ntiles = (LEAF / (2 * b)) * per;
-            // T = X22 L21 (X22 lower triangular: k <= row)
-            for (int t = wave; t < ntiles; t += LT / 64) {
-                const int p = t / per, tt = t - p * per, ti = tb - 1 - tt % tb, tj = tt / tb;   // heavy row tiles first
-                const int o = 2 * b * p, o2 = o + b;
-                const int row = 16 * ti + l15;
-                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                for (int kb = 0; kb < 16 * (ti + 1); kb += 16) {
-                    double xa[4], lb[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = kb + 4 * u + l4;
-                        xa[u] = (k <= row) ? s[(o2 + k) * LLD + o2 + row] : 0.0;
-                        lb[u] = s[(o + 16 * tj + l15) * LLD + o2 + k];
-                    }
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], lb[0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], lb[1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], lb[2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], lb[3], acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) scr[(16 * tj + l15) * LLD + b * p + 16 * ti + 4 * r + l4] = acc0[r] + acc1[r];
-            }
-            __syncthreads();
-            mark(6);
-            // X21 = -T X11 (X11 lower triangular: k >= column), written over L21
-            for (int t = wave; t < ntiles; t += LT / 64) {
-                const int p = t / per, tt = t - p * per, ti = tt % tb, tj = tt / tb;
-                const int o = 2 * b * p, o2 = o + b;
-                const int col = 16 * tj + l15;
-                double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                for (int kb = 16 * tj; kb < b; kb += 16) {
-                    double ta[4], xb[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int k = kb + 4 * u + l4;
-                        ta[u] = scr[k * LLD + b * p + 16 * ti + l15];
-                        xb[u] = (k >= col) ? s[(o + col) * LLD + o + k] : 0.0;
-                    }
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[0], xb[0], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[1], xb[1], acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[2], xb[2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[3], xb[3], acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[(o + col) * LLD + o2 + 16 * ti + 4 * r + l4] = -(acc0[r] + acc1[r]);
-            }
-            __syncthreads();
-            mark(5);
-        }
-    }
-#pragma unroll 8
-    for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
-        const int idx = it * LT + tid;
-        const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
-        const double v0 = (i >= c && i < nb && c < nb) ? s[c * LLD + i] : 0.0;
-        const double v1 = (i + 1 >= c && i + 1 < nb && c < nb) ? s[c * LLD + i + 1] : 0.0;
-        *reinterpret_cast<double2_t *>(inv + (size_t)i + (size_t)c * LEAF) = double2_t{v0, v1};
-    }
-    mark(7);
-    if (stamps && tid == 0)
-        for (int i = 0; i < 8; ++i) stamps[i] = ph[i];
-}
-
-constexpr int LEAF_LDS = LEAF * LLD + PW * (PW + 1) + PW;   // doubles of LDS leaf_body needs
 
 __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda, double *inv,
                                                   int *dinfo, int goff, int mode,

@@ -109,6 +109,11 @@ bool trsv_strips_ok(int n, const double *L, size_t ldl);
 int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state /* 4 ints, zero */,
                 hipStream_t st);
 
+// ---- batch.hip : many small fits (order <= 256 each) in one launch, one workgroup per problem
+int fit_batch_max_order();
+int fit_batch(int family, int nbatch, int npts, const double *x, const double *y, const double *z, const double *hyp,
+              int nhyp, const double *sig2n, unsigned flags, double *alpha, double *nll, int *info);
+
 // ---- blas_small.hip
 int zero_strict_upper(int n, double *A, size_t lda, hipStream_t st);
 int sym_fill_upper(int n, double *A, size_t lda, hipStream_t st);

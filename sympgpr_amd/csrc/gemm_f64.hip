@@ -152,6 +152,20 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
                         if (first < 0) first = 0;
                         if (first < m) elems += (double)(m - first);
                     }
+                } else if (lower) {
+                    // local piece of a block-cyclic matrix: element (i, j) counts iff its GLOBAL position is
+                    // on or below the diagonal: block (i / blk) pr + pi against (j / blk) pc + pj, then the
+                    // offsets inside the block
+                    elems = 0.0;
+                    const long blk = bc[0];
+                    for (long j = 0; j < n; ++j) {
+                        const long cbg = (j / blk) * bc[3] + bc[4], jo = j % blk;
+                        for (long rb = 0; rb * blk < m; ++rb) {
+                            const long rbg = rb * bc[1] + bc[2], rows = std::min(blk, (long)m - rb * blk);
+                            if (rbg > cbg) elems += (double)rows;
+                            else if (rbg == cbg) elems += (double)std::max(0L, rows - jo);
+                        }
+                    }
                 }
                 rec.flop = 2.0 * k * elems;
                 rec.m = m; rec.n = n; rec.k = k; rec.lower = lower; rec.overlap = t_overlap;

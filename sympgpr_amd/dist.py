@@ -7,9 +7,12 @@ on grid position (I mod pr, J mod pc).  Per panel step K of the right-looking fa
     owner of (K,K):      factor the diagonal block (sgpr_potrf_dev)
     process column K%pc: receives L_KK + its leaf inverses, solves its panel pieces
                          L(I,K) = A(I,K) L_KK^-T (sgpr_trsm_rlt_dev)
-    everyone:            pr broadcasts deliver the panel pieces of the pr process rows (RCCL
-                         broadcast over xGMI); the pieces needed as the column operand are
-                         regrouped by block
+    process rows:        rank (q, K%pc) broadcasts its solved pieces L(I,K), I = q mod pr, along
+                         process row q  -> every rank has the ROW operand of its update
+    process columns:     rank (q, j) hands the blocks J = q mod pr, J = j mod pc of that piece down
+                         process column j -> every rank has the COLUMN operand L(J,K), J = j mod pc
+                         (RCCL broadcasts on row / column sub-communicators over xGMI: a rank
+                         receives n/pr + n/pc rows of the panel, not all n)
     everyone:            local trailing update A(I,J) -= L(I,K) L(J,K)^T on the blocks it owns
                          (sgpr_gemm_nt_bc_dev, fp64 MFMA, tiles above the global diagonal
                          skipped) -- block column K+1 first, so that panel K+1 can be factored
@@ -113,6 +116,18 @@ class HipOps:
     def sync(self):
         torch.cuda.synchronize(self.device)
 
+    def side(self):
+        """Context of a second HIP stream: the column exchange of panel K+1 is packed and issued there,
+        behind the row broadcast it depends on, while this stream runs the bulk of update K."""
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self._side)
+
+    def join_side(self):
+        if hasattr(self, "_side"):
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+
 
 class DistFit:
     """Ky = build_K(x,x) + |sig2n| I, L, alpha, nll on a pr x pc grid.  All ranks call every
@@ -135,13 +150,14 @@ class DistFit:
         self.pi, self.pj = self.rank % self.pr, self.rank // self.pr
         self.N = len(x)
         self.n = 2 * self.d * self.N
-        self.nb = nb
-        if self.N % nb:
-            raise ValueError("the number of training points must be a multiple of the block size nb")
+        # Block size: the largest divisor of N that does not exceed the request and is a multiple of the
+        # 128-row leaf (any divisor for small test problems).  One pair per point (the reference's layout)
+        # takes any N / nb; d > 1 needs N / nb divisible by both grid dimensions (see build()).
+        lcm = self.pr * self.pc // math.gcd(self.pr, self.pc)
+        self.nb = self._pick_nb(self.N, nb, 1 if self.d == 1 else lcm)
+        nb = self.nb
         self.nbk = self.n // nb
         nbN = self.N // nb
-        if nbN % self.pr or nbN % self.pc:
-            raise ValueError("N/nb = %d must be a multiple of the grid dimensions %dx%d" % (nbN, self.pr, self.pc))
         self.hyp = np.asarray(hyp, dtype=np.float64)
         self.sig2n = abs(float(sig2n))
         self.rows = list(range(self.pi, self.nbk, self.pr))   # global block rows held here
@@ -164,30 +180,57 @@ class DistFit:
         self.nll = None
         self.info = 0
 
+    @staticmethod
+    def _pick_nb(N, want, mult):
+        """largest nb <= want with N % nb == 0 and (N / nb) % mult == 0, preferring multiples of 128"""
+        cands = [b for b in range(1, min(want, N) + 1) if N % b == 0 and (N // b) % mult == 0]
+        if not cands:
+            raise ValueError("no block size <= %d divides N = %d with N/nb a multiple of %d" % (want, N, mult))
+        aligned = [b for b in cands if b % 128 == 0]
+        return max(aligned) if aligned else max(cands)
+
     def grank(self, pi, pj):
         return pi + pj * self.pr
 
     # ------------------------------------------------------------------ Gram build (no comm)
     def build(self):
-        """Each rank evaluates the pairs of its own blocks.  Local rows are the q-rows of its
-        block rows followed by their P-rows (N/nb is a multiple of pr, pc), so the local matrix
-        is again [[qq, qP], [Pq, PP]] over the SELECTED row / column points."""
+        """Each rank evaluates the pairs of its own blocks (inputs replicated, no collective).
+        Global block row I < N/nb holds q-rows of the points of point-block I, the others P-rows of
+        point-block I - N/nb; this rank's local rows are its q-type block rows followed by its P-type
+        ones.  When N/nb is a multiple of the grid dimension both halves select the SAME points and the
+        local matrix is again [[qq, qP], [Pq, PP]] over that selection (one kernel launch); otherwise the
+        four parts are built over their own selections (sgpr_gram_pairs_dev takes the parts one by one)."""
         ops, nb, N = self.ops, self.nb, self.N
         nbN = N // nb
-        rsel = np.concatenate([np.arange(I * nb, (I + 1) * nb) for I in self.rows if I < nbN])
-        csel = np.concatenate([np.arange(J * nb, (J + 1) * nb) for J in self.cols if J < nbN])
         dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ops.device)
-        mi, mj = len(rsel), len(csel)
+        sel = lambda blocks: (np.concatenate([np.arange(B * nb, (B + 1) * nb) for B in blocks])
+                              if blocks else np.zeros(0, dtype=np.int64))
         ld = self.mloc
-        if self.X is None:
-            xb, yb, xa, ya = dev(self.x[rsel]), dev(self.y[rsel]), dev(self.x[csel]), dev(self.y[csel])
-            offs = [0, mi, mj * ld, mi + mj * ld]   # qq, Pq, qP, PP
-            ops.gram_pairs(self.family, mi, mj, xb, yb, xa, ya, self.hyp, self.A, offs, ld, L.G_ALL)
-        else:
+        if self.X is not None:
             # d pairs: the same row / column selection in each of the 2d coordinate blocks
+            rsel = sel([I for I in self.rows if I < nbN])
+            csel = sel([J for J in self.cols if J < nbN])
+            mi, mj = len(rsel), len(csel)
             Xb = dev(np.asfortranarray(self.X[rsel]).T.copy()).reshape(-1)   # (mi x 2d) column-major, flat
             Xa = dev(np.asfortranarray(self.X[csel]).T.copy()).reshape(-1)
             ops.gram_nd(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld)
+        else:
+            rq, rP = sel([I for I in self.rows if I < nbN]), sel([I - nbN for I in self.rows if I >= nbN])
+            cq, cP = sel([J for J in self.cols if J < nbN]), sel([J - nbN for J in self.cols if J >= nbN])
+            nrq, ncq = len(rq), len(cq)
+            offs = [0, nrq, ncq * ld, nrq + ncq * ld]             # qq, Pq, qP, PP inside the local matrix
+            if np.array_equal(rq, rP) and np.array_equal(cq, cP):
+                xb, yb, xa, ya = dev(self.x[rq]), dev(self.y[rq]), dev(self.x[cq]), dev(self.y[cq])
+                ops.gram_pairs(self.family, nrq, ncq, xb, yb, xa, ya, self.hyp, self.A, offs, ld, L.G_ALL)
+            else:
+                parts = ((L.G_QQ, rq, cq), (L.G_PQ, rP, cq), (L.G_QP, rq, cP), (L.G_PP, rP, cP))
+                for k, (flag, rs, cs) in enumerate(parts):
+                    if len(rs) == 0 or len(cs) == 0:
+                        continue
+                    po = [None] * 4
+                    po[k] = offs[k]
+                    ops.gram_pairs(self.family, len(rs), len(cs), dev(self.x[rs]), dev(self.y[rs]), dev(self.x[cs]),
+                                   dev(self.y[cs]), self.hyp, self.A, po, ld, flag)
         # |sig2n| on the global diagonal: the diagonal blocks this rank owns
         for li, I in enumerate(self.rows):
             if I % self.pc == self.pj:
@@ -196,9 +239,18 @@ class DistFit:
                 blk.diagonal().add_(self.sig2n)
 
     # ------------------------------------------------------------------ factorisation
+    def _buffers(self, K):
+        """Operand buffers of panel K (two sets: panel K+1 is in flight while update K runs)."""
+        if not hasattr(self, "_bufs"):
+            nb, mk = self.nb, lambda cnt: self.ops.empty(max(cnt, 1) * self.nb * self.nb)
+            per_q = [len([J for J in self.cols if J % self.pr == q]) for q in range(self.pr)]
+            self._bufs = [{"row": mk(len(self.rows)), "col": mk(len(self.cols)), "stage": [mk(c) for c in per_q]}
+                          for _ in range(2)]
+        return self._bufs[K & 1]
+
     def _panel_start(self, K):
-        """Factor the diagonal block K, solve its panel, START the broadcasts of the panel pieces
-        (one per process row, asynchronous).  Returns (pieces, handles)."""
+        """Factor the diagonal block K, solve its panel, START the broadcast of this process row's
+        solved pieces along the process row (asynchronous).  Returns (row piece, handles)."""
         ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
         kI, kJ = K % pr, K % pc
         lj_K = K // pc
@@ -207,9 +259,10 @@ class DistFit:
             blk = self.A2[lj_K * nb:(lj_K + 1) * nb, li_K * nb:(li_K + 1) * nb]
             self.Lkk.view(nb, nb).copy_(blk)
             ops.potrf(nb, self.Lkk, self.wbuf, self.info_t)
-            # LAPACK-style global index of the first failing minor, tracked on the device
-            cand = torch.where(self.info_t[:1] != 0, self.info_t[:1].to(torch.int64) + K * nb,
-                               torch.full_like(self.fail_t, self._BIG))
+            # LAPACK-style global index of the first failing minor, tracked on the device; a negative
+            # value (an internal error of the factor kernel) is kept as it is
+            i64 = self.info_t[:1].to(torch.int64)
+            cand = torch.where(i64 > 0, i64 + K * nb, torch.where(i64 < 0, i64, torch.full_like(i64, self._BIG)))
             self.fail_t = torch.minimum(self.fail_t, cand)
             blk.copy_(self.Lkk.view(nb, nb))
             self.work[K] = self.wbuf.clone()
@@ -217,49 +270,88 @@ class DistFit:
         m_p = self.mloc - li0 * nb
         if pj == kJ:
             src = self.grank(kI, kJ)
-            dist.broadcast(self.Lkk, src=src, group=self.col_groups[kJ])
-            dist.broadcast(self.wbuf, src=src, group=self.col_groups[kJ])
+            if pr > 1:
+                dist.broadcast(self.Lkk, src=src, group=self.col_groups[kJ])
+                dist.broadcast(self.wbuf, src=src, group=self.col_groups[kJ])
+                self.comm_bytes += 8 * (self.Lkk.numel() + self.wbuf.numel()) * (self.rank != src)
             if m_p > 0:
                 ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, li0 * nb + lj_K * nb * self.mloc, self.mloc)
-        pieces, handles = [], []
-        for q in range(pr):
-            lq0 = _count_le(K, q, pr)
-            nblk_q = len(range(q, self.nbk, pr)) - lq0
-            P = ops.empty(nblk_q * nb * nb)
-            if nblk_q > 0:
-                if (pi, pj) == (q, kJ):
-                    P.view(nb, nblk_q * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, lq0 * nb:])
-                handles.append(dist.broadcast(P, src=self.grank(q, kJ), group=self.group, async_op=True))
-            pieces.append((P, nblk_q, lq0))
-        return pieces, handles
+        nrow_blk = len(self.rows) - li0
+        Lrow = self._buffers(K)["row"][:nrow_blk * nb * nb]
+        handles = []
+        if nrow_blk > 0:
+            if pj == kJ:
+                Lrow.view(nb, nrow_blk * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, li0 * nb:])
+            if pc > 1:
+                handles.append(dist.broadcast(Lrow, src=self.grank(pi, kJ), group=self.row_groups[pi], async_op=True))
+                self.comm_bytes += 8 * Lrow.numel() * (pj != kJ)
+        return (Lrow, nrow_blk, li0), handles
 
-    def _operands(self, K, pieces):
-        """Row / column operands of this rank's trailing update for panel K."""
-        ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
-        Lrow, nrow_blk, _ = pieces[pi]
+    def _col_plan(self, K):
+        """For each process row q: which of my column blocks J > K it supplies (J = q mod pr), as
+        (q, first position t_q in my column list, stride, count, first position in q's row piece, stride)."""
+        pr, pc, pj = self.pr, self.pc, self.pj
         lj0 = _count_le(K, pj, pc)            # first local block column with J > K
         ncol_blk = len(self.cols) - lj0
+        plan = []
+        if ncol_blk > 0:
+            J0 = self.cols[lj0]
+            g = math.gcd(pc, pr)
+            period, pstep = pr // g, pc // g
+            for q in range(pr):
+                if (q - J0) % g:
+                    continue
+                t_q = next(t for t in range(period) if (J0 + pc * t) % pr == q)
+                cnt = len(range(t_q, ncol_blk, period))
+                if cnt:
+                    pos0 = (J0 + pc * t_q) // pr - _count_le(K, q, pr)
+                    plan.append((q, t_q, period, cnt, pos0, pstep))
+        return lj0, ncol_blk, plan
+
+    def _col_exchange_start(self, K, rowpiece):
+        """Second half of the panel exchange: every rank of process row q now holds L(I,K), I = q mod pr;
+        rank (q, pj) hands the blocks that are also column blocks of process column pj down that column.
+        Called behind the row broadcast (which it reads); returns (state, handles)."""
+        nb, pr, pi = self.nb, self.pr, self.pi
+        Lrow, nrow_blk, _ = rowpiece
+        lj0, ncol_blk, plan = self._col_plan(K)
+        buf = self._buffers(K)
+        handles, stages = [], []
+        for (q, t_q, period, cnt, pos0, pstep) in plan:
+            st = buf["stage"][q][:cnt * nb * nb]
+            if pi == q:
+                st.view(nb, cnt, nb).copy_(Lrow.view(nb, nrow_blk, nb)[:, pos0:pos0 + (cnt - 1) * pstep + 1:pstep, :])
+            if pr > 1:
+                handles.append(dist.broadcast(st, src=self.grank(q, self.pj), group=self.col_groups[self.pj], async_op=True))
+                self.comm_bytes += 8 * st.numel() * (pi != q)
+            stages.append((st, t_q, period, cnt))
+        return (lj0, ncol_blk, stages, buf), handles
+
+    def _col_finish(self, state):
+        """Regroup the received blocks by local column: a handful of strided device copies (no index
+        tensors, no host sync)."""
+        nb = self.nb
+        lj0, ncol_blk, stages, buf = state
+        if ncol_blk == 0:
+            return None, 0, lj0
+        Lcol = buf["col"][:ncol_blk * nb * nb]
+        Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
+        for (st, t_q, period, cnt) in stages:
+            Lc3[:, t_q::period, :] = st.view(nb, cnt, nb)
+        return Lcol, ncol_blk, lj0
+
+    def _exchange(self, K):
+        """panel K: factor / solve / both broadcast phases, waited for (used for panel 0)."""
+        rowp, h = self._panel_start(K)
+        for x in h:
+            x.wait()
+        state, h2 = self._col_exchange_start(K, rowp)
+        for x in h2:
+            x.wait()
+        Lcol, ncol_blk, lj0 = self._col_finish(state)
+        Lrow, nrow_blk, _ = rowp
         if nrow_blk == 0 or ncol_blk == 0:
             return None
-        Lcol = ops.empty(ncol_blk * nb * nb)
-        Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
-        # Column block t is global block J = J0 + pc t and sits in the piece of process row J % pr at
-        # position J // pr - lq0.  For a fixed q those t form an arithmetic progression, so the
-        # regrouping is a handful of strided device copies -- no index tensors, no host sync (a
-        # host-to-device index upload per step would serialise the look-ahead).
-        J0 = self.cols[lj0]
-        g = math.gcd(pc, pr)
-        period, pstep = pr // g, pc // g
-        for q in range(pr):
-            P, nblk_q, lq0 = pieces[q]
-            if nblk_q == 0 or (q - J0) % g:
-                continue
-            t_q = next(t for t in range(period) if (J0 + pc * t) % pr == q)
-            cnt = len(range(t_q, ncol_blk, period))
-            if cnt == 0:
-                continue
-            pos0 = (J0 + pc * t_q) // pr - lq0
-            Lc3[:, t_q::period, :] = P.view(nb, nblk_q, nb)[:, pos0:pos0 + (cnt - 1) * pstep + 1:pstep, :]
         return Lrow, nrow_blk, Lcol, ncol_blk, lj0
 
     def _update(self, K, opnd, c_from, c_to):
@@ -282,29 +374,43 @@ class DistFit:
 
     def factor(self):
         """Right-looking with one step of look-ahead: while the bulk of trailing update K runs,
-        panel K+1 (already updated) is factored, solved and on its way to the other ranks."""
+        panel K+1 (already updated) is factored, solved and on its way to the other ranks: its row
+        broadcast starts at once, its column exchange behind it on a side stream."""
         self.info = 0
+        self.comm_bytes = 0
         self.fail_t = torch.full((1,), self._BIG, dtype=torch.int64, device=self.info_t.device)
-        pieces, handles = self._panel_start(0)
-        for h in handles:
-            h.wait()
+        side = getattr(self.ops, "side", None)
+        opnd = self._exchange(0)
         for K in range(self.nbk):
-            opnd = self._operands(K, pieces)
-            nxt = None
             if K + 1 < self.nbk:
                 owns_next = (K + 1) % self.pc == self.pj   # block column K+1 is my first column > K
                 if owns_next:
                     self._update(K, opnd, 0, 1)
-                nxt = self._panel_start(K + 1)
-                self._update(K, opnd, 1 if owns_next else 0, 1 << 30)
-                pieces, handles = nxt
-                for h in handles:
-                    h.wait()
+                rowp, h1 = self._panel_start(K + 1)
+                if side is not None:
+                    with side():                           # behind the row broadcast, beside the bulk update
+                        for x in h1:
+                            x.wait()
+                        state, h2 = self._col_exchange_start(K + 1, rowp)
+                    self._update(K, opnd, 1 if owns_next else 0, 1 << 30)
+                    self.ops.join_side()
+                else:
+                    for x in h1:
+                        x.wait()
+                    state, h2 = self._col_exchange_start(K + 1, rowp)
+                    self._update(K, opnd, 1 if owns_next else 0, 1 << 30)
+                for x in h1 + h2:
+                    x.wait()
+                Lcol, ncol_blk, lj0 = self._col_finish(state)
+                Lrow, nrow_blk, _ = rowp
+                opnd = None if (nrow_blk == 0 or ncol_blk == 0) else (Lrow, nrow_blk, Lcol, ncol_blk, lj0)
             else:
                 self._update(K, opnd, 0, 1 << 30)
         t = self.fail_t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         v = int(t.item())
+        if v < 0:
+            raise L.SympGPRError("the factor kernel reported an internal error (%d) on some rank" % v)
         self.info = 0 if v >= self._BIG else v
         return self.info
 

@@ -25,6 +25,7 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
     else:
         X, z, hyp, s2 = synth_pairs(n_pts, d)
         fit = DistFit(ops, args.family, None, None, z, hyp, s2, nb=nb, X=X)
+    nb = fit.nb      # the driver may have picked a smaller block size that divides N
 
     def barrier():
         dist.barrier()
@@ -63,6 +64,20 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
     dist.all_reduce(st, op=dist.ReduceOp.MAX)
     ms_per_step = float(dt.item()) / args.steps * 1e3
     stage = st.cpu().numpy()
+    cb = torch.tensor([float(fit.comm_bytes)], dtype=torch.float64, device=dev)   # bytes this rank received
+    cb_max, cb_sum = cb.clone(), cb.clone()
+    dist.all_reduce(cb_max, op=dist.ReduceOp.MAX)
+    dist.all_reduce(cb_sum, op=dist.ReduceOp.SUM)
+
+    # roofline pass: one more (untimed, collective) step with a HIP-event pair around every launch of the
+    # MFMA kernel; rank 0's launches are reported
+    prof = np.zeros(12)
+    if not getattr(args, "no_launch_events", False):
+        from . import _lib as L_
+        L_.check(ops.lib.sgpr_profile_begin())
+        step(False)
+        torch.cuda.synchronize()
+        L_.check(ops.lib.sgpr_profile_end(L_.dptr(prof)))
 
     # parity evidence: residual of Ky alpha = z on a sample of rows, rebuilt from the inputs
     a = fit.alpha.cpu().numpy()
@@ -106,11 +121,29 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
             "gram_gb_s": 8.0 * n * n / (stage[0] * 1e-3) / 1e9, "gram_ms": stage[0],
             "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12, "chol_ms": stage[1],
             "solve_ms": stage[2], "residual_Ky_alpha_minus_z": resid, "nll": fit.nll,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (local trailing updates)",
-                         "achieved": chol_flop / (stage[1] * 1e-3) / 1e12 / world,
-                         "peak": peaks["mfma"], "unit": "TFLOP/s per GPU (factor stage incl. RCCL panel broadcasts)",
-                         "frac": chol_flop / (stage[1] * 1e-3) / 1e12 / world / peaks["mfma"], "traffic": None},
+            "panel_bytes_received_per_step": {"max_over_ranks": float(cb_max.item()), "sum_over_ranks": float(cb_sum.item()),
+                                              "note": "row broadcast along the process row + column exchange down the "
+                                                      "process column + L_KK and its leaf inverses; a rank receives "
+                                                      "(1/pr + 1/pc) of every panel"},
         }
+        n_l, fl, ms_l = prof[0] + prof[8], prof[1] + prof[9], prof[2] + prof[10]
+        if n_l > 0 and ms_l > 0:
+            ach = fl / (ms_l * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (rank 0's local trailing updates)",
+                               "achieved": ach, "peak": peaks["mfma"], "unit": "TFLOP/s", "frac": ach / peaks["mfma"],
+                               "traffic": None, "traffic_source": None,
+                               "timing": "one untimed extra step, HIP-event pair per launch on rank 0",
+                               "launches": int(n_l), "flop_per_launch": fl / n_l, "avg_launch_ms": ms_l / n_l,
+                               "per_gpu_factor_stage_tflops": chol_flop / (stage[1] * 1e-3) / 1e12 / world}
+        else:
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (local trailing updates)",
+                               "achieved": chol_flop / (stage[1] * 1e-3) / 1e12 / world, "peak": peaks["mfma"],
+                               "unit": "TFLOP/s per GPU (factor stage incl. RCCL panel broadcasts)",
+                               "frac": chol_flop / (stage[1] * 1e-3) / 1e12 / world / peaks["mfma"], "traffic": None}
+        if cpu_baseline is not None and getattr(args, "cpu_sample", 0) > 0:
+            # the same bounded CPU sample as the one-GPU line (rank 0 only; the other ranks wait at the barrier)
+            cbl, _, _ = cpu_baseline(args.family if d == 1 else "A", args.cpu_sample)
+            out["cpu_baseline"] = cbl
         print(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()

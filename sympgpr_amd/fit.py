@@ -178,3 +178,31 @@ class SympFit:
         dA, lda, dal = C.c_void_p(), C.c_size_t(), C.c_void_p()
         L.check(self._lib.sgpr_fit_device_ptrs(self._h, C.byref(dA), C.byref(lda), C.byref(dal)))
         return dA.value, lda.value, dal.value
+
+
+def batch_max_order():
+    """largest matrix order per problem sgpr_fit_batch takes (256)"""
+    return L.load_library().sgpr_fit_batch_max_order()
+
+
+def fit_batch(family, x, y, z, hyp, sig2n, reg=False, want_alpha=True):
+    """Many small independent fits in ONE launch (one workgroup per problem): the body of nll_chol
+    (python/functions/func.py:189-196; reg=True: nll_chol_reg) for every row b of
+        x, y (B, n_pts);  z (B, n), n = 2 n_pts (n_pts with reg);  hyp (B, nhyp);  sig2n (B,) or scalar.
+    -> (alpha (B, n) or None, nll (B,), info (B,)): info[b] > 0 where Ky_b is not positive definite
+    (nll[b] is NaN there, like the LinAlgError scipy raises for that problem)."""
+    x, y, z, hyp = (np.ascontiguousarray(np.atleast_2d(np.asarray(v, dtype=np.float64))) for v in (x, y, z, hyp))
+    B, n_pts = x.shape
+    n = n_pts if reg else 2 * n_pts
+    if y.shape != (B, n_pts) or z.shape != (B, n) or hyp.shape[0] != B:
+        raise ValueError("fit_batch: x, y (B, n_pts), z (B, n), hyp (B, nhyp)")
+    s2 = np.ascontiguousarray(np.broadcast_to(np.asarray(sig2n, dtype=np.float64), (B,)))
+    alpha = np.empty((B, n)) if want_alpha else None
+    nll = np.empty(B)
+    info = np.zeros(B, dtype=np.int32)
+    L.check(L.load_library().sgpr_fit_batch(L.family_id(family), B, n_pts, L.dptr(x), L.dptr(y), L.dptr(z), L.dptr(hyp),
+                                            hyp.shape[1], L.dptr(s2), L.FIT_REG if reg else 0,
+                                            L.dptr(alpha) if want_alpha else None, L.dptr(nll),
+                                            info.ctypes.data_as(C.POINTER(C.c_int))), "sgpr_fit_batch")
+    nll[info != 0] = np.nan
+    return alpha, nll, info

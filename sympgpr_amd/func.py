@@ -103,6 +103,36 @@ def nll_chol(hyp, x, y, N):
         return f.run().nll()
 
 
+def nll_chol_batch(hyps, x, y, N, reg=False):
+    """nll_chol (reg=True: nll_chol_reg) for a whole POPULATION of hyper-parameter vectors over the same
+    data in one launch: what a CMA-ES generation costs the Split_SympGPR driver one call at a time
+    (python/05_tokamak/Split_SympGPR/main.py:36-41,63-66: `cma.fmin(nll_transform, ...)`).
+    hyps (B, nhyp + 1) rows like nll_chol's hyp (the last entry is sig2_n); N = matrix order, at most
+    fit.batch_max_order() (larger orders: loop over nll_chol).  Rows whose Ky is not positive
+    definite come back as +inf (an optimiser's usual penalty for an exception)."""
+    from .fit import batch_max_order, fit_batch
+    hyps = np.atleast_2d(np.asarray(hyps, dtype=np.float64))
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if N > batch_max_order():
+        f = nll_chol_reg if reg else nll_chol
+        out = np.empty(len(hyps))
+        for b, h in enumerate(hyps):
+            try:
+                out[b] = f(h, x, y, N)
+            except np.linalg.LinAlgError:
+                out[b] = np.inf
+        return out
+    npts = N if reg else N // 2
+    B = len(hyps)
+    X = np.broadcast_to(x[0:npts], (B, npts))
+    Y = np.broadcast_to(x[npts:2 * npts], (B, npts))
+    Z = np.broadcast_to(y[:N if reg else 2 * npts], (B, N if reg else 2 * npts))
+    _, nll, info = fit_batch(get_family(), X, Y, Z, hyps[:, :-1], np.abs(hyps[:, -1]), reg=reg, want_alpha=False)
+    nll[info != 0] = np.inf
+    return nll
+
+
 def guessP(x, y, hypp, xtrainp, ztrainp, Kyinvp):
     """functions/func.py:198-201."""
     Ntrain = len(xtrainp) // 2

@@ -23,12 +23,25 @@ def fit_sections(family, xtrain, ztrain, hyp, sig2n, reg=False, rank=0, world=1,
     """xtrain (2N x nphmap) columns (q || P), ztrain (n x nphmap) with n = 2N (N with reg=True),
     hyp (nphmap x 3) rows (lx, ly, sig).  Returns {m: (alpha_m, nll_m)} for the sections this rank
     owns.  fit_fn(family, x, y, z, hyp, sig2n, reg) -> (alpha, nll) defaults to the device fit."""
-    fit_fn = fit_fn or _hip_fit
     xtrain, ztrain, hyp = np.asarray(xtrain), np.asarray(ztrain), np.atleast_2d(hyp)
     nphmap = xtrain.shape[1]
     N = xtrain.shape[0] // 2
     out = {}
-    for m in owned_sections(nphmap, rank, world):
+    mine = owned_sections(nphmap, rank, world)
+    if fit_fn is None and mine:
+        # the sections of this rank in ONE launch (one workgroup per section) while the order allows it:
+        # at the drivers' sizes (order 40 ... 160) a fit through a handle is all set-up time
+        from .fit import batch_max_order, fit_batch
+        if (N if reg else 2 * N) <= batch_max_order():
+            sel = np.array(mine)
+            al, nll, info = fit_batch(family, xtrain[:N, sel].T, xtrain[N:2 * N, sel].T, ztrain[:, sel].T, hyp[sel],
+                                      sig2n, reg=reg)
+            if np.any(info):
+                raise np.linalg.LinAlgError("section %d: %d-th leading minor of the array is not positive definite"
+                                            % (int(sel[np.nonzero(info)[0][0]]), int(info[np.nonzero(info)[0][0]])))
+            return {int(m): (al[k].copy(), float(nll[k])) for k, m in enumerate(sel)}
+    fit_fn = fit_fn or _hip_fit
+    for m in mine:
         out[m] = fit_fn(family, xtrain[:N, m], xtrain[N:2 * N, m], ztrain[:, m], hyp[m], sig2n, reg)
     return out
 

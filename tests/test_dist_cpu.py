@@ -90,7 +90,10 @@ def _run(world, N, nb, fam="A", singular=False):
     return dict(out)
 
 
-@pytest.mark.parametrize("world,N,nb", [(2, 32, 4), (4, 32, 4), (4, 64, 8), (6, 48, 4), (1, 24, 4), (8, 64, 4)])
+# the last four: N / nb NOT a multiple of the grid dimensions (the q-rows and the P-rows a rank holds
+# then belong to different points: the four parts of K are built over their own selections)
+@pytest.mark.parametrize("world,N,nb", [(2, 32, 4), (4, 32, 4), (4, 64, 8), (6, 48, 4), (1, 24, 4), (8, 64, 4),
+                                        (2, 20, 4), (4, 36, 4), (6, 40, 4), (3, 28, 4)])
 def test_block_cyclic_fit_matches_oracle(oracle, world, N, nb):
     res = _run(world, N, nb)
     rng = np.random.default_rng(1234)
@@ -128,6 +131,17 @@ def test_block_cyclic_not_pd_reports_same_info_everywhere():
     Ky = Oracle().build_K("A", q, P, q, P, [l, l, -4.0]) + 2.0 / l**2 * np.eye(2 * N)
     expect = scipy.linalg.lapack.dpotrf(Ky, lower=1)[1]
     assert expect > 0 and infos == {expect}
+
+
+def test_block_size_is_picked_to_divide():
+    from sympgpr_amd.dist import DistFit
+    assert DistFit._pick_nb(65536, 2048, 1) == 2048
+    assert DistFit._pick_nb(65536, 3000, 1) == 2048
+    assert DistFit._pick_nb(12800, 2048, 1) == 1280          # multiple of 128 dividing N
+    assert DistFit._pick_nb(12288, 2048, 4) == 1536          # N / nb = 8, a multiple of 4
+    assert DistFit._pick_nb(40, 16, 1) == 10
+    with pytest.raises(ValueError):
+        DistFit._pick_nb(7, 4, 2)
 
 
 def test_grid_shape():

@@ -1,0 +1,130 @@
+"""GPU parity of the batched small fits (sgpr_fit_batch: one workgroup per problem, one launch) against
+the CPU oracle, problem by problem -- the reference's only batch axis (Split_SympGPR's nphmap sections
+and CMA-ES populations over nll_chol, python/05_tokamak/Split_SympGPR/main.py:36-41,63-66,96-112)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HYP = {"A": [0.55, 0.8, 1.3], "B": [0.55, 0.8, 1.3], "C": [0.9, 0.8, 1.3], "D": [0.55, 0.8, 0.7, 1.3]}
+
+
+def _problems(rng, B, n_pts, fam):
+    x = rng.uniform(0, 2 * np.pi, (B, n_pts))
+    y = rng.uniform(-3, 3, (B, n_pts))
+    hyp = np.array(HYP[fam]) * rng.uniform(0.8, 1.25, (B, len(HYP[fam])))
+    s2 = rng.uniform(1e-3, 1e-2, B)
+    return x, y, hyp, s2
+
+
+@pytest.mark.parametrize("fam", ["A", "B", "C", "D"])
+@pytest.mark.parametrize("n_pts", [1, 7, 20, 40, 64, 65, 80, 100, 128])
+def test_fit_batch_vs_oracle(oracle, fam, n_pts):
+    """orders 2 ... 256: one leaf (n <= 128) and the two-leaf path (128 < n <= 256), ragged sizes"""
+    from sympgpr_amd.fit import fit_batch
+    rng = np.random.default_rng(100 * n_pts + ord(fam))
+    B = 5
+    x, y, hyp, s2 = _problems(rng, B, n_pts, fam)
+    z = rng.standard_normal((B, 2 * n_pts))
+    al, nll, info = fit_batch(fam, x, y, z, hyp, s2)
+    assert np.all(info == 0)
+    for b in range(B):
+        if fam == "D":
+            Ko = oracle.build_K(fam, x[b], y[b], x[b], y[b], hyp[b])
+            Lf = oracle.cholesky(Ko + s2[b] * np.eye(2 * n_pts))
+            a_o = oracle.solve_cholesky(Lf, z[b])
+            nll_o = oracle.nll(Lf, z[b], a_o)
+        else:
+            a_o, nll_o, _ = oracle.fit(fam, x[b], y[b], z[b], hyp[b], s2[b])
+        cond = np.linalg.cond(oracle.build_K(fam, x[b], y[b], x[b], y[b], hyp[b]) + s2[b] * np.eye(2 * n_pts))
+        assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < max(1e-10, 50 * cond * 2.2e-16)
+        assert nll[b] == pytest.approx(nll_o, rel=1e-10, abs=1e-10)
+
+
+@pytest.mark.parametrize("n_pts", [30, 128, 200])
+def test_fit_batch_reg_vs_oracle(oracle, n_pts):
+    """the scalar-kernel GP (nll_chol_reg, functions/func.py:180-187): order n = n_pts"""
+    from sympgpr_amd.fit import fit_batch
+    rng = np.random.default_rng(n_pts)
+    B = 4
+    x, y, hyp, s2 = _problems(rng, B, n_pts, "A")
+    z = rng.standard_normal((B, n_pts))
+    al, nll, info = fit_batch("A", x, y, z, hyp, s2, reg=True)
+    assert np.all(info == 0)
+    for b in range(B):
+        Ky = oracle.buildKreg("A", x[b], y[b], x[b], y[b], hyp[b]) + s2[b] * np.eye(n_pts)
+        Lf = oracle.cholesky(Ky)
+        a_o = oracle.solve_cholesky(Lf, z[b])
+        assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < max(1e-10, 50 * np.linalg.cond(Ky) * 2.2e-16)
+        assert nll[b] == pytest.approx(oracle.nll(Lf, z[b], a_o), rel=1e-10)
+
+
+def test_fit_batch_many_problems_and_not_pd(oracle):
+    """more problems than workgroups in flight; one of them indefinite (sig < 0): its info is the LAPACK
+    index dpotrf reports, the others are unaffected"""
+    import scipy.linalg
+    from sympgpr_amd.fit import fit_batch
+    rng = np.random.default_rng(5)
+    B, n_pts = 1500, 20
+    x, y, hyp, s2 = _problems(rng, B, n_pts, "A")
+    z = rng.standard_normal((B, 2 * n_pts))
+    bad = 777
+    hyp[bad, -1] = -4.0
+    s2[bad] = 0.5
+    al, nll, info = fit_batch("A", x, y, z, hyp, s2)
+    Kbad = oracle.build_K("A", x[bad], y[bad], x[bad], y[bad], hyp[bad]) + s2[bad] * np.eye(2 * n_pts)
+    expect = scipy.linalg.lapack.dpotrf(Kbad, lower=1)[1]
+    assert expect > 0 and info[bad] == expect and np.isnan(nll[bad])
+    assert np.count_nonzero(info) == 1
+    for b in (0, 1, 776, 778, 1499):
+        a_o, nll_o, _ = oracle.fit("A", x[b], y[b], z[b], hyp[b], s2[b])
+        assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < 1e-9
+        assert nll[b] == pytest.approx(nll_o, rel=1e-10)
+
+
+def test_nll_chol_batch_is_nll_chol_per_row(oracle):
+    """a CMA-ES generation: nll_chol for a population of hyper-parameter vectors over the same data"""
+    from sympgpr_amd import func
+    rng = np.random.default_rng(9)
+    Np = 40
+    x = np.hstack((rng.uniform(0, 2 * np.pi, Np), rng.uniform(-3, 3, Np)))
+    yv = rng.standard_normal(2 * Np)
+    hyps = np.column_stack((rng.uniform(0.3, 1.0, 12), rng.uniform(0.4, 1.2, 12), rng.uniform(0.5, 2.0, 12),
+                            rng.uniform(1e-3, 1e-2, 12)))
+    hyps[5, 2] = -3.0                                  # not positive definite -> +inf
+    hyps[5, 3] = 0.1
+    func.set_family("A")
+    got = func.nll_chol_batch(hyps, x, yv, 2 * Np)
+    for b, h in enumerate(hyps):
+        if b == 5:
+            assert np.isinf(got[b])
+            continue
+        _, nll_o, _ = oracle.fit("A", x[:Np], x[Np:], yv, h[:-1], abs(h[-1]))
+        assert got[b] == pytest.approx(nll_o, rel=1e-10)
+        assert got[b] == pytest.approx(func.nll_chol(h, x, yv, 2 * Np), rel=1e-12)
+    # the quirk of the drivers' first stage: the symplectic objective on an N x N matrix
+    got_half = func.nll_chol_batch(hyps[:3], x, yv, Np)
+    for b in range(3):
+        assert got_half[b] == pytest.approx(func.nll_chol(hyps[b], x, yv, Np), rel=1e-12)
+    # scalar-kernel objective
+    got_reg = func.nll_chol_batch(hyps[:3], x, yv[:Np], Np, reg=True)
+    for b in range(3):
+        assert got_reg[b] == pytest.approx(func.nll_chol_reg(hyps[b], x, yv[:Np], Np), rel=1e-12)
+
+
+def test_sections_use_one_launch(oracle):
+    """Split_SympGPR's nphmap sections through sections.fit_sections: batched on the device, equal to the
+    per-section oracle fits"""
+    from sympgpr_amd import sections
+    rng = np.random.default_rng(13)
+    nph, Np = 4, 80                                   # order 160: the drivers' largest
+    xtrain = np.vstack((rng.uniform(0, 2 * np.pi, (Np, nph)), rng.uniform(-3, 3, (Np, nph))))
+    ztrain = rng.standard_normal((2 * Np, nph))
+    hyp = np.column_stack((rng.uniform(0.4, 0.7, nph), rng.uniform(0.6, 0.9, nph), np.ones(nph)))
+    loc = sections.fit_sections("A", xtrain, ztrain, hyp, 1e-3)
+    assert sorted(loc) == list(range(nph))
+    for m in range(nph):
+        a_o, nll_o, _ = oracle.fit("A", xtrain[:Np, m], xtrain[Np:, m], ztrain[:, m], hyp[m], 1e-3)
+        cond = 2e5
+        assert np.linalg.norm(loc[m][0] - a_o) / np.linalg.norm(a_o) < 50 * cond * 2.2e-16
+        assert loc[m][1] == pytest.approx(nll_o, rel=1e-10)

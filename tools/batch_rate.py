@@ -1,0 +1,71 @@
+"""Fits per second of the batched small-fit launch (sgpr_fit_batch) at the drivers' own sizes, beside (a) one
+nll_chol at a time through a device-resident handle and (b) the reference's CPU path for the same call
+(its compiled Fortran build_K from oracle/_ref + the SciPy cholesky / solve_triangular of
+python/functions/func.py:189-196, one thread, as the reference runs it).
+python tools/batch_rate.py [orders...]   (default 80 160)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sympgpr_amd import func
+from sympgpr_amd.fit import fit_batch
+
+
+def cpu_nll(ref, x, y, z, hyp, s2):
+    import scipy.linalg
+    K = ref.build_K("A", x, y, x, y, hyp)
+    K[np.diag_indices(len(z))] += abs(s2)
+    Lf = scipy.linalg.cholesky(K, lower=True, check_finite=False)
+    a = scipy.linalg.solve_triangular(Lf.T, scipy.linalg.solve_triangular(Lf, z, lower=True, check_finite=False),
+                                      lower=False, check_finite=False)
+    return 0.5 * z @ a + np.sum(np.log(Lf.diagonal()))
+
+
+def main():
+    orders = [int(a) for a in sys.argv[1:]] or [80, 160]
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=1)
+    except Exception:
+        limit = None
+    from oracle.oracle import Oracle, Ref
+    ref = Ref() if Ref.available() else None
+    rng = np.random.default_rng(3)
+    func.set_family("A")
+    print("| order n | batch size | batched launch | one handle per call | reference CPU path (1 thread) |")
+    print("|---|---|---|---|---|")
+    for n in orders:
+        Np = n // 2
+        for B in (4, 64, 1024):
+            x, y = rng.uniform(0, 2 * np.pi, (B, Np)), rng.uniform(-3, 3, (B, Np))
+            z = rng.standard_normal((B, n))
+            l = 2.0 * np.sqrt(12 * np.pi / Np)
+            hyp = np.tile([l, l, 1.0], (B, 1))
+            s2 = np.full(B, 1e-2 / l**2)
+            fit_batch("A", x, y, z, hyp, s2)
+            reps = max(1, 2000 // B)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                _, nll, info = fit_batch("A", x, y, z, hyp, s2, want_alpha=False)
+            tb = (time.perf_counter() - t0) / (reps * B)
+            m = min(B, 64)
+            t0 = time.perf_counter()
+            one = [func.nll_chol(np.append(hyp[b], s2[b]), np.hstack((x[b], y[b])), z[b], n) for b in range(m)]
+            th = (time.perf_counter() - t0) / m
+            assert np.allclose(one, nll[:m], rtol=1e-10)
+            if ref is not None:
+                t0 = time.perf_counter()
+                cpu = [cpu_nll(ref, x[b], y[b], z[b], hyp[b], s2[b]) for b in range(m)]
+                tc = (time.perf_counter() - t0) / m
+                assert np.allclose(cpu, nll[:m], rtol=1e-9)
+                cpu_s = "%.0f fits/s (%.0f us)" % (1 / tc, tc * 1e6)
+            else:
+                cpu_s = "n/a"
+            print("| %d | %d | %.0f fits/s (%.1f us) | %.0f fits/s (%.0f us) | %s |" % (n, B, 1 / tb, tb * 1e6, 1 / th, th * 1e6, cpu_s))
+
+
+if __name__ == "__main__":
+    main()
