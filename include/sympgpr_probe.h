@@ -32,6 +32,13 @@ int sgpr_probe_xcc(int nblocks, int *host_out);
 /* the same on a stream restricted by a CU mask (hipExtStreamCreateWithCUMask): out[2b] = XCC id, out[2b+1] = HW_ID */
 int sgpr_probe_cumask(const unsigned *mask_words, int nwords, int nblocks, int *host_out);
 
+/* The OUTPUT OF THE CODE GENERATOR (tools/gen_kernels.py -> csrc/generated/pair_generated.h), evaluated as
+ * it stands: out[i] = f(xa[i], ya[i], xb[i], yb[i], l...) without the sig factor; `which` as in
+ * sgpr_kernel_eval_host (0..3 = k, d2k/dxdx0, d2k/dydy0, d2k/dxdy0; | 4: d/dlx; | 8: d/dly).  The product
+ * library's hand-optimised kernels are diffed against this in tests/test_gpu_generated.py. */
+int sgpr_probe_generated_eval(int family, int which, int m, const double *xa, const double *ya,
+                              const double *xb, const double *yb, const double *l, int nl, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@
 ! lie under /root/reference by oracle/Makefile and are never copied into the repo.
 module sympgpr_ref_shim
     use iso_c_binding
-    use sympgpr, only: build_K, buildKreg, guessP, calcq, calcP
+    use sympgpr, only: build_K, buildKreg, guessP, calcq, calcP, applymap_tok
     implicit none
 contains
 
@@ -51,5 +51,20 @@ function ref_calcp(x, y, hyp, hypp, np, xtrainp, ytrainp, ztrainp, Kyinvp, &
     r = calcP(x, y, hyp, hypp, xtrainp, ytrainp, ztrainp, Kyinvp, &
         xtrain, ytrain, ztrain, Kyinv)
 end function
+
+! applymap_tok (sympgpr.f90:128-177): qmap, pmap are [nm, Ntest, 1] in/out, as the f2py wrapper passes them
+subroutine ref_applymap_tok(nm, ntest, hyp, hypp, Q0map, P0map, np, xtrainp, ytrainp, ztrainp, Kyinvp, &
+        nt, xtrain, ytrain, ztrain, Kyinv, qmap, pmap) bind(C, name="ref_applymap_tok")
+    integer(c_int), value :: nm, ntest, np, nt
+    real(c_double), intent(in) :: hyp(3), hypp(3), Q0map(ntest), P0map(ntest)
+    real(c_double), intent(in) :: xtrainp(np), ytrainp(np), ztrainp(np), Kyinvp(np, np)
+    real(c_double), intent(in) :: xtrain(nt), ytrain(nt), ztrain(2*nt), Kyinv(2*nt, 2*nt)
+    real(c_double), intent(inout) :: qmap(nm, ntest, 1), pmap(nm, ntest, 1)
+    integer :: nm_, ntest_
+    nm_ = nm
+    ntest_ = ntest
+    call applymap_tok(nm_, ntest_, hyp, hypp, Q0map, P0map, xtrainp, ytrainp, ztrainp, Kyinvp, &
+        xtrain, ytrain, ztrain, Kyinv, qmap, pmap)
+end subroutine
 
 end module sympgpr_ref_shim

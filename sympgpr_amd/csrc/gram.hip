@@ -492,10 +492,6 @@ int gram_pairs(int family, int mi, int mj, const double *xb, const double *yb, c
     if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
     const bool ocml = flags & SGPR_G_OCML;
     const int deriv = (flags & SGPR_G_DLX) ? DERIV_LX : ((flags & SGPR_G_DLY) ? DERIV_LY : DERIV_NONE);
-    if (deriv != DERIV_NONE && family == SGPR_FAM_B) {
-        set_error("length-scale derivatives are not available for the sum kernel (family B)");
-        return SGPR_E_ARG;
-    }
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
         if (deriv == DERIV_LX)      hipLaunchKernelGGL((gram_pairs_kernel<F, false, DERIV_LX>), grid, dim3(GT), 0, st, a);
@@ -511,10 +507,6 @@ int gram_reg(int family, int mi, int mj, const double *xb, const double *yb, con
              const double *ya, const KConst &kc, double *G, size_t ld, long diag_off, double noise,
              hipStream_t st, int deriv)
 {
-    if (deriv != DERIV_NONE && family == SGPR_FAM_B) {
-        set_error("length-scale derivatives are not available for the sum kernel (family B)");
-        return SGPR_E_ARG;
-    }
     if (mi < 0 || mj < 0) { set_error("negative extent"); return SGPR_E_ARG; }
     if (mi == 0 || mj == 0) return 0;
     if (ld < (size_t)mi) { set_error("ld smaller than the tile's row count"); return SGPR_E_ARG; }
@@ -546,10 +538,6 @@ int kernel_eval(int family, int which, int m, const double *xa, const double *ya
     const int deriv = which >> 2;
     which &= 3;
     if (deriv < 0 || deriv > 2) { set_error("unknown kernel function"); return SGPR_E_ARG; }
-    if (deriv != DERIV_NONE && family == SGPR_FAM_B) {
-        set_error("length-scale derivatives are not available for the sum kernel (family B)");
-        return SGPR_E_ARG;
-    }
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
         const dim3 grid((m + 255) / 256);

@@ -5,6 +5,7 @@
 #pragma once
 #include "common.h"
 #include "devmath.h"
+#include "generated/pair_generated.h"
 
 namespace sgpr {
 namespace pairf {
@@ -64,7 +65,17 @@ template <int FAM, int DL>
 __device__ __forceinline__ void pair_eval_d(double xa, double ya, double xb, double yb,
                                             const KConst &kc, double &dxx, double &dxy, double &dyy)
 {
-    static_assert(FAM != SGPR_FAM_B, "length-scale derivatives are implemented for the product kernels");
+    if constexpr (FAM == SGPR_FAM_B) {
+        // the sum kernel's dl-functions (kernels_sum.f90:133-208) come straight from the generator
+        // (tools/gen_kernels.py): no driver differentiates this family, nothing to hand-optimise
+        double o[4];
+        if constexpr (DL == DERIV_LX) gen::pair_dlx<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        else                          gen::pair_dly<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        dxx = kc.sig * o[1];
+        dyy = kc.sig * o[2];
+        dxy = kc.sig * o[3];
+        return;
+    }
     const double dy = ya - yb;
     const double v = dy * dy;
     double u, E, kxx, kxy, kyy, gp;  // gp = g'(lx)/gxx for the xx entry
@@ -105,7 +116,12 @@ __device__ __forceinline__ void pair_eval_d(double xa, double ya, double xb, dou
 template <int FAM, int DL>
 __device__ __forceinline__ double kern_eval_d(double xa, double ya, double xb, double yb, const KConst &kc)
 {
-    static_assert(FAM != SGPR_FAM_B, "length-scale derivatives are implemented for the product kernels");
+    if constexpr (FAM == SGPR_FAM_B) {
+        double o[4];
+        if constexpr (DL == DERIV_LX) gen::pair_dlx<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        else                          gen::pair_dly<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        return o[0];
+    }
     const double dy = ya - yb;
     const double v = dy * dy;
     double u;
@@ -150,14 +166,12 @@ __device__ __forceinline__ void pair_any(double xa, double ya, double xb, double
                                          double &kxx, double &kxy, double &kyy)
 {
     if constexpr (DL == DERIV_NONE) pair_eval<FAM, OCML>(xa, ya, xb, yb, kc, kxx, kxy, kyy);
-    else if constexpr (FAM == SGPR_FAM_B) { kxx = kxy = kyy = __builtin_nan(""); }
     else pair_eval_d<FAM, DL>(xa, ya, xb, yb, kc, kxx, kxy, kyy);
 }
 template <int FAM, bool OCML, int DL>
 __device__ __forceinline__ double kern_any(double xa, double ya, double xb, double yb, const KConst &kc)
 {
     if constexpr (DL == DERIV_NONE) return kern_eval<FAM, OCML>(xa, ya, xb, yb, kc);
-    else if constexpr (FAM == SGPR_FAM_B) return __builtin_nan("");
     else return kern_eval_d<FAM, DL>(xa, ya, xb, yb, kc);
 }
 

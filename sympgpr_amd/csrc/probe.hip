@@ -7,6 +7,7 @@
 
 #include "common.h"
 #include "../../include/sympgpr_probe.h"
+#include "generated/pair_generated.h"
 
 namespace sgpr {
 namespace {
@@ -288,5 +289,49 @@ extern "C" int sgpr_probe_cumask(const unsigned *mask_words, int nwords, int nbl
     SGPR_HIP(hipMemcpy(host_out, d, sizeof(int) * 2 * nblocks, hipMemcpyDeviceToHost));
     (void)hipFree(d);
     (void)hipStreamDestroy(st);
+    return 0;
+}
+
+
+// ---- the generator's output, evaluated as it stands (tests/test_gpu_generated.py diffs the hand-optimised
+// kernels of pair_eval.h against it)
+namespace sgpr {
+template <int FAM>
+__global__ void generated_eval_kernel(int which, int m, const double *xa, const double *ya, const double *xb,
+                                      const double *yb, double lx, double ly, double p, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double o[4];
+    const int dl = which >> 2;
+    if (dl == 0)      gen::pair<FAM>(xa[i], ya[i], xb[i], yb[i], lx, ly, p, o);
+    else if (dl == 1) gen::pair_dlx<FAM>(xa[i], ya[i], xb[i], yb[i], lx, ly, p, o);
+    else              gen::pair_dly<FAM>(xa[i], ya[i], xb[i], yb[i], lx, ly, p, o);
+    out[i] = o[which & 3];
+}
+}  // namespace sgpr
+
+extern "C" int sgpr_probe_generated_eval(int family, int which, int m, const double *xa, const double *ya,
+                                         const double *xb, const double *yb, const double *l, int nl, double *out)
+{
+    using namespace sgpr;
+    if (m <= 0) return 0;
+    if (which < 0 || which > 11 || !l || nl < 2 || (family == SGPR_FAM_D && nl < 3)) { set_error("generated_eval: bad arguments"); return SGPR_E_ARG; }
+    double *d[5] = {};
+    const double *h[4] = {xa, ya, xb, yb};
+    for (int k = 0; k < 5; ++k) SGPR_HIP(hipMalloc((void **)&d[k], sizeof(double) * m));
+    for (int k = 0; k < 4; ++k) SGPR_HIP(hipMemcpy(d[k], h[k], sizeof(double) * m, hipMemcpyHostToDevice));
+    const double p = family == SGPR_FAM_D ? l[2] : 0.0;
+    const dim3 grid((m + 255) / 256);
+    switch (family) {
+    case SGPR_FAM_A: hipLaunchKernelGGL(generated_eval_kernel<SGPR_FAM_A>, grid, dim3(256), 0, nullptr, which, m, d[0], d[1], d[2], d[3], l[0], l[1], p, d[4]); break;
+    case SGPR_FAM_B: hipLaunchKernelGGL(generated_eval_kernel<SGPR_FAM_B>, grid, dim3(256), 0, nullptr, which, m, d[0], d[1], d[2], d[3], l[0], l[1], p, d[4]); break;
+    case SGPR_FAM_C: hipLaunchKernelGGL(generated_eval_kernel<SGPR_FAM_C>, grid, dim3(256), 0, nullptr, which, m, d[0], d[1], d[2], d[3], l[0], l[1], p, d[4]); break;
+    case SGPR_FAM_D: hipLaunchKernelGGL(generated_eval_kernel<SGPR_FAM_D>, grid, dim3(256), 0, nullptr, which, m, d[0], d[1], d[2], d[3], l[0], l[1], p, d[4]); break;
+    default: set_error("unknown kernel family"); return SGPR_E_ARG;
+    }
+    SGPR_CHECK_LAUNCH();
+    SGPR_HIP(hipMemcpy(out, d[4], sizeof(double) * m, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 5; ++k) (void)hipFree(d[k]);
     return 0;
 }

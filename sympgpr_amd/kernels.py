@@ -4,8 +4,8 @@ the same device code the Gram kernels use (sgpr_kernel_eval_host).  Arguments ma
 (-> float, like f2py) or broadcastable arrays (-> array, one batched launch).
 
 All 19 functions of a generated kernels*.f90 are here: the four above, the eight length-scale
-derivatives build_dK / build_dKreg call (kernels.f90:133-231; product kernels A, C, D only -- the
-sum kernel's driver never differentiates with respect to l), and the seven no caller in the
+derivatives build_dK / build_dKreg call (kernels.f90:133-231; for the sum kernel, kernels_sum.f90:133-208,
+straight from the code generator tools/gen_kernels.py), and the seven no caller in the
 reference uses (dkdx, dkdy, dkdx0, dkdy0 and the three d3k...dy0 functions, kernels.f90:12-57,95-132)."""
 from . import _lib as L
 from . import ops
