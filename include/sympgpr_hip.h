@@ -87,9 +87,10 @@ int sgpr_buildkreg_host(int family, int n, int n0, const double *x, const double
                         double *K, size_t ldk);
 /* d canonical pairs per point (BASELINE configs d = 2, 3; SURVEY.md 8 preamble): X (n x 2d), X0
  * (n0 x 2d) column-major, one column per coordinate (q_1..q_d, P_1..P_d), hyp = (lq_1..lq_d,
- * lP_1..lP_d, sig).  K is (2 d n x 2 d n0): block (a, b) = sig d^2 k / dx_a dx'_b at rows a n,
- * columns b n0, for the product kernel of family A (periodic q's) or C (all SE).  d = 1 is
- * sgpr_build_k_host entry for entry; d > 1 has no counterpart in the reference. */
+ * lP_1..lP_d, sig) -- (lq.., lP.., p_1..p_d, sig) for family D.  K is (2 d n x 2 d n0): block (a, b) =
+ * sig d^2 k / dx_a dx'_b at rows a n, columns b n0, for the product kernel of family A (periodic q's),
+ * C (all SE) or D (a free period per q), or the sum kernel B (only the diagonal blocks are non-zero).
+ * d = 1 is sgpr_build_k_host entry for entry; d > 1 has no counterpart in the reference. */
 int sgpr_build_k_nd_host(int family, int d, int n, int n0, const double *X, size_t ldx,
                          const double *X0, size_t ldx0, const double *hyp, int nhyp, double *K,
                          size_t ldk);

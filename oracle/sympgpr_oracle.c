@@ -125,7 +125,8 @@ double orc_scalar(int fam, int which, double x_a, double y_a, double x_b, double
  * 03_henon_heiles/main.py:155).  Expressions as generated:
  *   A: python/05_tokamak/SympGPR/kernels.f90:135-231 (dkdlx, dkdly, d3kdxdx0dlx, d3kdydy0dlx,
  *      d3kdxdy0dlx, d3kdxdx0dly, d3kdydy0dly, d3kdxdy0dly)
- *   C: python/03_henon_heiles/kernels_sq.f90:124-217 */
+ *   C: python/03_henon_heiles/kernels_sq.f90:124-217
+ *   B: python/01_pendulum/explicit/kernels_sum.f90:120-208 */
 double orc_scalar_dl(int fam, int which, double x_a, double y_a, double x_b, double y_b,
                      double lx, double ly)
 {
@@ -164,6 +165,24 @@ double orc_scalar_dl(int fam, int which, double x_a, double y_a, double x_b, dou
         case W_DYDY0DLY:
             return (-2.0 * ly2 * ly2 + 5.0 * ly2 * sq(dy) - 1.0 * sq(sq(dy))) * E / (ly2 * ly2 * ly2 * ly);
         case W_DXDY0DLY: return (2.0 * ly2 - 1.0 * sq(dy)) * dx * dy * E / (lx2 * ly2 * ly2 * ly);
+        }
+    } else if (fam == FAM_B) {
+        /* python/01_pendulum/explicit/kernels_sum.f90:120-208: the sum kernel's factors separate; the
+         * Fortran writes (y_a - y_b)^2 expanded (:139, :178-181) -- kept, so the cancellation is the same one */
+        const double s = sin(0.5 * x_a - 0.5 * x_b), c = cos(0.5 * x_a - 0.5 * x_b);
+        const double cd = cos(1.0 * x_a - 1.0 * x_b);
+        const double ex = exp(-0.5 * sq(s) / lx2);
+        const double ey = exp((-0.5 * sq(y_a) + 1.0 * y_a * y_b - 0.5 * sq(y_b)) / ly2);
+        switch (which) {
+        case W_DKDLX: return 1.0 * ex * sq(s) / (lx2 * lx);
+        case W_DKDLY: return (sq(y_a) - 2.0 * y_a * y_b + sq(y_b)) * ey / (ly2 * ly);
+        case W_DXDX0DLX:
+            return (-0.5 * lx2 * lx2 * cd + lx2 * (0.75 * cd + 0.5) * sq(s) - 0.25 * sq(sq(s)) * sq(c)) * ex /
+                   (lx2 * lx2 * lx2 * lx);
+        case W_DYDY0DLY:
+            return (-2.0 * ly2 * ly2 + ly2 * (1.0 * sq(y_a) - 2.0 * y_a * y_b + 1.0 * sq(y_b) + 4.0 * sq(dy)) +
+                    sq(dy) * (-1.0 * sq(y_a) + 2.0 * y_a * y_b - 1.0 * sq(y_b))) * ey / (ly2 * ly2 * ly2 * ly);
+        case W_DYDY0DLX: case W_DXDY0DLX: case W_DXDX0DLY: case W_DXDY0DLY: return 0.0;   /* INTEGER*4 ... = 0 */
         }
     }
     return NAN;
@@ -441,30 +460,38 @@ void orc_predict_reg(int fam, int m, const double *q, const double *P, int n0,
 int orc_build_k_nd(int fam, int d, int n, int n0, const double *X, const double *X0, const double *hyp,
                    double *K, size_t ldk)
 {
+    /* families B (sum kernel: k = sum_m f_m, K_aa = -sig f_a'', other blocks zero) and D (free period p_m per
+     * q, hyp = (lq.., lP.., p_1..p_d, sig)) generalise the same way; d = 1 is their build_K. */
     const int D = 2 * d;
-    const double sig = hyp[D];
-    if (fam != FAM_A && fam != FAM_C) return -1;
+    const double sig = hyp[fam == FAM_D ? 3 * d : D];
+    if (fam < FAM_A || fam > FAM_D) return -1;
     for (int j = 0; j < n0; ++j)
         for (int i = 0; i < n; ++i) {
-            double g[16], nh[16], arg = 0.0;
+            double g[16], nh[16], ar[16], arg = 0.0;
             for (int m = 0; m < D; ++m) {
                 const double l = hyp[m], l2 = l * l;
                 const double dx = X0[j + (size_t)m * n0] - X[i + (size_t)m * n];   /* a = column point */
-                if (m < d && fam == FAM_A) {
-                    const double s = sin(0.5 * dx), c = cos(0.5 * dx);
-                    arg += -0.5 * s * s / l2;
-                    g[m] = -0.5 * s * c / l2;
-                    nh[m] = 0.25 * (l2 * cos(dx) - s * s * c * c) / (l2 * l2);
+                if (m < d && fam != FAM_C) {
+                    const double hs = fam == FAM_D ? hyp[D + m] : 0.5;
+                    const double s = sin(hs * dx), c = cos(hs * dx);
+                    ar[m] = -0.5 * s * s / l2;
+                    g[m] = -hs * s * c / l2;
+                    nh[m] = hs * hs * (l2 * cos(2.0 * hs * dx) - s * s * c * c) / (l2 * l2);
                 } else {
-                    arg += -0.5 * dx * dx / l2;
+                    ar[m] = -0.5 * dx * dx / l2;
                     g[m] = -dx / l2;
                     nh[m] = (l2 - dx * dx) / (l2 * l2);
                 }
+                arg += ar[m];
             }
             const double E = sig * exp(arg);
             for (int a = 0; a < D; ++a)
-                for (int b = 0; b < D; ++b)
-                    K[(size_t)a * n + i + ((size_t)b * n0 + j) * ldk] = E * (a == b ? nh[a] : -g[a] * g[b]);
+                for (int b = 0; b < D; ++b) {
+                    double v;
+                    if (fam == FAM_B) v = a == b ? sig * exp(ar[a]) * nh[a] : 0.0;
+                    else v = E * (a == b ? nh[a] : -g[a] * g[b]);
+                    K[(size_t)a * n + i + ((size_t)b * n0 + j) * ldk] = v;
+                }
         }
     return 0;
 }

@@ -51,7 +51,8 @@ using namespace sgpr;
 struct sgpr_fit {
     int family = 0, npts = 0, n = 0;
     int d = 1;                 // canonical pairs per point (1 = the reference's layout)
-    double hyp_nd[8] = {};     // (lq.., lP.., sig) for d > 1
+    double hyp_nd[12] = {};    // (lq.., lP.., [p..,] sig) for d > 1
+    int nhyp_nd = 0;
     double *dX = nullptr;      // all coordinates, (npts x 2d) column-major; dx = dX, dy = dX + npts
     unsigned flags = 0;
     hipStream_t st = nullptr;
@@ -341,12 +342,14 @@ static int fit_create_common(int family, int d, int n_pts, const double *X, size
     if (d == 1) {
         if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
     } else {
-        if (d < 1 || d > 3 || nhyp != 2 * d + 1 || !hyp || (family != SGPR_FAM_A && family != SGPR_FAM_C)) {
+        const int need = family == SGPR_FAM_D ? 3 * d + 1 : 2 * d + 1;
+        if (d < 1 || d > 3 || nhyp != need || !hyp || family < SGPR_FAM_A || family > SGPR_FAM_D) {
             delete f;
-            set_error("fit_create_nd: d in 1..3, family A or C, hyp = (lq_1..lq_d, lP_1..lP_d, sig)");
+            set_error("fit_create_nd: d in 1..3, hyp = (lq_1..lq_d, lP_1..lP_d, sig) -- (lq.., lP.., p_1..p_d, sig) for family D");
             return SGPR_E_ARG;
         }
         for (int i = 0; i < nhyp; ++i) f->hyp_nd[i] = hyp[i];
+        f->nhyp_nd = nhyp;
     }
     f->sig2n = sig2n;
     const size_t n = (size_t)f->n;
@@ -401,7 +404,7 @@ int sgpr_fit_set_hyp(sgpr_fit_t f, const double *hyp, int nhyp, double sig2n)
 {
     if (!f) { set_error("null fit"); return SGPR_E_ARG; }
     if (f->d > 1) {
-        if (!hyp || nhyp != 2 * f->d + 1) { set_error("fit_set_hyp: hyp = (lq.., lP.., sig)"); return SGPR_E_ARG; }
+        if (!hyp || nhyp != f->nhyp_nd) { set_error("fit_set_hyp: hyp = (lq.., lP.., [p..,] sig)"); return SGPR_E_ARG; }
         for (int i = 0; i < nhyp; ++i) f->hyp_nd[i] = hyp[i];
     } else {
         int rc = make_kconst(f->family, hyp, nhyp, &f->kc);
@@ -432,7 +435,7 @@ static int fit_build_impl(sgpr_fit_t f, bool lower_only)
     int rc;
     if (f->d > 1) {
         // d canonical pairs: (2d)^2 blocks of N x N, block (a, b) at rows a N, columns b N
-        rc = gram_nd(f->family, f->d, N, N, f->dX, (size_t)N, f->dX, (size_t)N, f->hyp_nd, 2 * f->d + 1, f->dA, n,
+        rc = gram_nd(f->family, f->d, N, N, f->dX, (size_t)N, f->dX, (size_t)N, f->hyp_nd, f->nhyp_nd, f->dA, n,
                      (size_t)N, (size_t)N, 0, std::fabs(f->sig2n), f->st);
     } else if (f->flags & SGPR_FIT_REG) {
         // Ky = buildKreg(x, x) + |sig2n| I  (func.py:182-183)
@@ -768,9 +771,12 @@ int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, doub
     if ((rc = dT.alloc((size_t)m * D * sizeof(double))) || (rc = dO.alloc((size_t)m * D * sizeof(double)))) return rc;
     SGPR_HIP(hipMemcpy2DAsync(dT.p, (size_t)m * sizeof(double), Xt, ldxt * sizeof(double), (size_t)m * sizeof(double), D,
                               hipMemcpyHostToDevice, f->st));
-    double hyp1[3] = {f->kc.lx, f->kc.ly, f->kc.sig};
+    double hyp1[4] = {f->kc.lx, f->kc.ly, f->kc.sig, 0.0};
+    int nh1 = 3;
+    if (f->family == SGPR_FAM_D) { hyp1[2] = f->kc.p; hyp1[3] = f->kc.sig; nh1 = 4; }
     const double *hyp = f->d > 1 ? f->hyp_nd : hyp1;
-    if ((rc = predict_nd(f->family, f->d, m, dT.as<double>(), (size_t)m, f->npts, f->dX, (size_t)f->npts, hyp, D + 1,
+    if ((rc = predict_nd(f->family, f->d, m, dT.as<double>(), (size_t)m, f->npts, f->dX, (size_t)f->npts, hyp,
+                         f->d > 1 ? f->nhyp_nd : nh1,
                          f->dalpha, dO.as<double>(), f->st)))
         return rc;
     SGPR_HIP(hipMemcpyAsync(out, dO.p, (size_t)m * D * sizeof(double), hipMemcpyDeviceToHost, f->st));

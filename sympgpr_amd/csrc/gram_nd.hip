@@ -2,9 +2,11 @@
 //
 // The reference's kernels take one pair (x, y) = (q, P) (kernels.f90:1); SURVEY.md 8 generalises
 // them the way its own generator would (init_func.py:24-52): inputs x = (q_1..q_d, P_1..P_d),
-// product kernel k = prod_m f_m(x_m - x'_m) with f_m periodic (family A) or SE (family C) on the q's
-// and SE on the P's, and the covariance of the gradient observations
-//     K_ab = d^2 k / dx_a dx'_b = sig k (a == b ? -f_a''/f_a : -(f_a'/f_a)(f_b'/f_b)),  a, b = 1..2d,
+// product kernel k = prod_m f_m(x_m - x'_m) with f_m periodic (family A; D: with a free period p_m per q,
+// hyp = (lq.., lP.., p_1..p_d, sig)) or SE (family C) on the q's and SE on the P's, and the covariance of
+// the gradient observations
+//     K_ab = d^2 k / dx_a dx'_b = sig k (a == b ? -f_a''/f_a : -(f_a'/f_a)(f_b'/f_b)),  a, b = 1..2d;
+// family B, the SUM kernel k = sum_m f_m: K_aa = -sig f_a'', all other blocks zero (the explicit maps),
 // stored as (2d)^2 blocks of N x N0, block (a, b) at rows a*N, columns b*N0.  d = 1 is build_K
 // (sympgpr.f90:12-38) entry for entry.  One exp and d sincos per PAIR feed all (2d)^2 entries:
 // 32 d^2 bytes written per pair, so the kernel is even more firmly HBM-write bound than d = 1.
@@ -27,22 +29,23 @@ struct NdArgs {
     long diag_off;
     double noise, sig;
     double l2[6], inv_l2[6], inv_l4[6];
+    double hs[6];            // periodic coordinates: sin(hs (x - x')), hs = 1/2 (A, B) or p_m (D)
 };
 
-// per coordinate: contribution to the exponent, g = f'/f, nh = -f''/f
+// per coordinate: exponent of f_m, g = f'/f, nh = -f''/f
 template <int FAM, int D, int M>
 __device__ __forceinline__ void coord(const NdArgs &a, double dx, double &arg, double &g, double &nh)
 {
-    if constexpr (FAM == SGPR_FAM_A && M < D / 2) {
+    if constexpr (FAM != SGPR_FAM_C && M < D / 2) {
         double s, c;
-        sincos_fast(0.5 * dx, s, c);
+        sincos_fast(a.hs[M] * dx, s, c);
         const double s2 = s * s, sc = s * c;
-        arg = __builtin_fma(-0.5 * a.inv_l2[M], s2, arg);
-        g = -0.5 * sc * a.inv_l2[M];
-        nh = 0.25 * (a.l2[M] * __builtin_fma(-2.0, s2, 1.0) - sc * sc) * a.inv_l4[M];
+        arg = -0.5 * a.inv_l2[M] * s2;
+        g = -a.hs[M] * sc * a.inv_l2[M];
+        nh = (a.hs[M] * a.hs[M]) * (a.l2[M] * __builtin_fma(-2.0, s2, 1.0) - sc * sc) * a.inv_l4[M];
     } else {
         const double d2 = dx * dx;
-        arg = __builtin_fma(-0.5 * a.inv_l2[M], d2, arg);
+        arg = -0.5 * a.inv_l2[M] * d2;
         g = -dx * a.inv_l2[M];
         nh = (a.l2[M] - d2) * a.inv_l4[M];
     }
@@ -50,11 +53,29 @@ __device__ __forceinline__ void coord(const NdArgs &a, double dx, double &arg, d
 
 template <int FAM, int D, int M = 0>
 __device__ __forceinline__ void all_coords(const NdArgs &a, const double *xa, const double (&xb)[D],
-                                           double &arg, double (&g)[D], double (&nh)[D])
+                                           double (&arg)[D], double (&g)[D], double (&nh)[D])
 {
     if constexpr (M < D) {
-        coord<FAM, D, M>(a, xa[M] - xb[M], arg, g[M], nh[M]);
+        coord<FAM, D, M>(a, xa[M] - xb[M], arg[M], g[M], nh[M]);
         all_coords<FAM, D, M + 1>(a, xa, xb, arg, g, nh);
+    }
+}
+
+// E[m]: the factor that multiplies nh[m] on the diagonal blocks -- sig k for the product kernels (one exp
+// per pair), sig f_m for the sum kernel (one exp per coordinate)
+template <int FAM, int D>
+__device__ __forceinline__ void weights(const NdArgs &a, const double (&arg)[D], double (&E)[D])
+{
+    if constexpr (FAM == SGPR_FAM_B) {
+#pragma unroll
+        for (int m = 0; m < D; ++m) E[m] = a.sig * exp_fast(arg[m]);
+    } else {
+        double t = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) t += arg[m];
+        const double e = a.sig * exp_fast(t);
+#pragma unroll
+        for (int m = 0; m < D; ++m) E[m] = e;
     }
 }
 
@@ -78,18 +99,21 @@ __global__ __launch_bounds__(NT) void gram_nd_kernel(const NdArgs a)
     const bool vec = (i0 + NTI <= a.mi) && (((a.ld | a.rstride | a.cstride) & 1) == 0) && (((uintptr_t)a.K & 15) == 0);
     const long d0 = (long)i + a.diag_off;
     for (int jj = 0; jj < nj; ++jj) {
-        double g0[D], nh0[D], g1[D], nh1[D], arg0 = 0.0, arg1 = 0.0;
+        double g0[D], nh0[D], g1[D], nh1[D], arg0[D], arg1[D], E0[D], E1[D];
         all_coords<FAM, D>(a, sxa[jj], xb0, arg0, g0, nh0);
         all_coords<FAM, D>(a, sxa[jj], xb1, arg1, g1, nh1);
-        const double E0 = a.sig * exp_fast(arg0), E1 = a.sig * exp_fast(arg1);
+        weights<FAM, D>(a, arg0, E0);
+        weights<FAM, D>(a, arg1, E1);
         const long j = j0 + jj;
         const double n0 = (d0 == j) ? a.noise : 0.0, n1 = (d0 + 1 == j) ? a.noise : 0.0;
 #pragma unroll
         for (int ca = 0; ca < D; ++ca) {
 #pragma unroll
             for (int cb = 0; cb < D; ++cb) {
-                const double k0 = (ca == cb) ? __builtin_fma(E0, nh0[ca], n0) : -E0 * (g0[ca] * g0[cb]);
-                const double k1 = (ca == cb) ? __builtin_fma(E1, nh1[ca], n1) : -E1 * (g1[ca] * g1[cb]);
+                const double off0 = (FAM == SGPR_FAM_B) ? 0.0 : -E0[ca] * (g0[ca] * g0[cb]);
+                const double off1 = (FAM == SGPR_FAM_B) ? 0.0 : -E1[ca] * (g1[ca] * g1[cb]);
+                const double k0 = (ca == cb) ? __builtin_fma(E0[ca], nh0[ca], n0) : off0;
+                const double k1 = (ca == cb) ? __builtin_fma(E1[ca], nh1[ca], n1) : off1;
                 double *dst = a.K + (size_t)ca * a.rstride + (size_t)i + ((size_t)cb * a.cstride + (size_t)j) * a.ld;
                 if (vec) {
                     *reinterpret_cast<double2_t *>(dst) = double2_t{k0, k1};
@@ -112,17 +136,19 @@ __global__ __launch_bounds__(NT) void predict_nd_kernel(const NdArgs a, int m, c
 #pragma unroll
     for (int c = 0; c < D; ++c) { xb[c] = a.Xb[(size_t)k + (size_t)c * a.ldxb]; acc[c] = 0.0; }
     for (int j = threadIdx.x; j < a.mj; j += NT) {
-        double xa[D], g[D], nh[D], arg = 0.0;
+        double xa[D], g[D], nh[D], arg[D], E[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) xa[c] = a.Xa[(size_t)j + (size_t)c * a.ldxa];
         all_coords<FAM, D>(a, xa, xb, arg, g, nh);
-        const double E = a.sig * exp_fast(arg);
+        weights<FAM, D>(a, arg, E);
         double al[D], S = 0.0;
 #pragma unroll
         for (int c = 0; c < D; ++c) { al[c] = alpha[(size_t)c * a.mj + j]; S = __builtin_fma(g[c], al[c], S); }
 #pragma unroll
-        for (int c = 0; c < D; ++c)  // sum_b K_cb alpha_b = E (nh_c al_c - g_c (S - g_c al_c))
-            acc[c] = __builtin_fma(E, __builtin_fma(nh[c], al[c], -g[c] * (S - g[c] * al[c])), acc[c]);
+        for (int c = 0; c < D; ++c) {  // sum_b K_cb alpha_b = E (nh_c al_c - g_c (S - g_c al_c)); sum kernel: E_c nh_c al_c
+            const double cross = (FAM == SGPR_FAM_B) ? 0.0 : -g[c] * (S - g[c] * al[c]);
+            acc[c] = __builtin_fma(E[c], __builtin_fma(nh[c], al[c], cross), acc[c]);
+        }
     }
     __shared__ double sh[NT / 64][D];
 #pragma unroll
@@ -142,14 +168,19 @@ __global__ __launch_bounds__(NT) void predict_nd_kernel(const NdArgs a, int m, c
 int fill_args(int family, int d, const double *hyp, int nhyp, NdArgs &a)
 {
     if (d < 1 || d > 3) { set_error("d must be 1, 2 or 3"); return SGPR_E_ARG; }
-    if (family != SGPR_FAM_A && family != SGPR_FAM_C) { set_error("d > 1 is available for families A and C"); return SGPR_E_ARG; }
-    if (!hyp || nhyp != 2 * d + 1) { set_error("hyp must hold (lq_1..lq_d, lP_1..lP_d, sig)"); return SGPR_E_ARG; }
+    if (family < SGPR_FAM_A || family > SGPR_FAM_D) { set_error("unknown kernel family"); return SGPR_E_ARG; }
+    const int need = family == SGPR_FAM_D ? 3 * d + 1 : 2 * d + 1;
+    if (!hyp || nhyp != need) {
+        set_error("hyp must hold (lq_1..lq_d, lP_1..lP_d, sig) -- (lq.., lP.., p_1..p_d, sig) for family D");
+        return SGPR_E_ARG;
+    }
     for (int m = 0; m < 2 * d; ++m) {
         a.l2[m] = hyp[m] * hyp[m];
         a.inv_l2[m] = 1.0 / a.l2[m];
         a.inv_l4[m] = a.inv_l2[m] * a.inv_l2[m];
+        a.hs[m] = (family == SGPR_FAM_D && m < d) ? hyp[2 * d + m] : 0.5;
     }
-    a.sig = hyp[2 * d];
+    a.sig = hyp[nhyp - 1];
     return 0;
 }
 
@@ -159,6 +190,8 @@ int dispatch_nd(int family, int d, F &&f)
 #define SGPR_ND_CASE(FAMV, DV) if (family == FAMV && d == DV) return f(std::integral_constant<int, FAMV>(), std::integral_constant<int, 2 * DV>())
     SGPR_ND_CASE(SGPR_FAM_A, 1); SGPR_ND_CASE(SGPR_FAM_A, 2); SGPR_ND_CASE(SGPR_FAM_A, 3);
     SGPR_ND_CASE(SGPR_FAM_C, 1); SGPR_ND_CASE(SGPR_FAM_C, 2); SGPR_ND_CASE(SGPR_FAM_C, 3);
+    SGPR_ND_CASE(SGPR_FAM_B, 1); SGPR_ND_CASE(SGPR_FAM_B, 2); SGPR_ND_CASE(SGPR_FAM_B, 3);
+    SGPR_ND_CASE(SGPR_FAM_D, 1); SGPR_ND_CASE(SGPR_FAM_D, 2); SGPR_ND_CASE(SGPR_FAM_D, 3);
 #undef SGPR_ND_CASE
     set_error("unsupported (family, d)");
     return SGPR_E_ARG;

@@ -386,5 +386,9 @@ def test_all_19_kernel_functions_vs_reference_fixture(golden_dir, fam):
             ref = np.array(ref, dtype=float)
             got = np.array([getattr(kernels, name)(a["x_a"][i], a["y_a"][i], a["x_b"][i], a["y_b"][i], a["lx"][i],
                                                    a["ly"][i], *(e[i] for e in extra)) for i in range(len(ref))])
-            assert np.all(np.abs(got - ref) <= 1e-13 * np.maximum(np.abs(ref), 1e-3)), name
+            # kernels_sum.f90:139 etc. write (y_a - y_b)^2 expanded (y_a**2 - 2 y_a y_b + y_b**2): for y_a ~ y_b
+            # the REFERENCE value carries that cancellation (5e-16 absolute at the fixture's closest pair, where
+            # the device value equals the exact one), so the sum kernel's dl-functions get an absolute 1e-14 on top
+            slack = 1e-14 if (fam == "B" and "dl" in name) else 0.0
+            assert np.all(np.abs(got - ref) <= 1e-13 * np.maximum(np.abs(ref), 1e-3) + slack), name
     assert len(g["values"]) == 19 and len(kernels.__all__) == 19

@@ -459,7 +459,7 @@ def test_mirror_applymap_vs_pointwise_reference(oracle):
 
 
 # ---------------------------------------------------------------- hyper-parameter gradients
-@pytest.mark.parametrize("fam", ["A", "C", "D"])
+@pytest.mark.parametrize("fam", ["A", "B", "C", "D"])
 def test_build_dK_vs_oracle(oracle, fam):
     from sympgpr_amd import func
     func.set_family(fam)
@@ -492,7 +492,7 @@ def test_build_dK_vs_oracle(oracle, fam):
         func.set_family("A")
 
 
-@pytest.mark.parametrize("fam,Np", [("A", 40), ("C", 150), ("A", 700)])
+@pytest.mark.parametrize("fam,Np", [("A", 40), ("C", 150), ("A", 700), ("B", 60)])
 def test_nll_grad_vs_oracle(oracle, fam, Np):
     """nll_grad / nll_grad_reg (functions/func.py:132-162) through the device path (two panel
     solves + a transpose instead of the explicit inverse) against the restated reference."""
@@ -594,12 +594,15 @@ def test_multi_rhs_solve_on_mfma(ops, n, nrhs):
 
 # ---------------------------------------------------------------- d canonical pairs (BASELINE d = 2, 3)
 @pytest.mark.parametrize("fam,d,n,n0", [("A", 1, 37, 21), ("A", 2, 600, 70), ("C", 2, 33, 1025), ("A", 3, 130, 64),
-                                        ("C", 3, 1, 5)])
+                                        ("C", 3, 1, 5), ("B", 2, 100, 31), ("D", 2, 65, 130), ("D", 3, 20, 20),
+                                        ("B", 1, 40, 9), ("D", 1, 40, 9)])
 def test_build_k_nd_vs_oracle(ops, oracle, fam, d, n, n0):
     rng = np.random.default_rng(1000 * d + n)
     X = np.column_stack([rng.uniform(0, 2 * np.pi, (n, d)), rng.uniform(-3, 3, (n, d))])
     X0 = np.column_stack([rng.uniform(0, 2 * np.pi, (n0, d)), rng.uniform(-3, 3, (n0, d))])
     hyp = np.append(rng.uniform(0.5, 1.5, 2 * d), 0.8)
+    if fam == "D":   # free period per q: (lq.., lP.., p_1..p_d, sig)
+        hyp = np.concatenate((hyp[:-1], rng.uniform(0.4, 0.9, d), hyp[-1:]))
     K = ops.build_k_nd(X, X0, hyp, family=fam)
     Ko = oracle.build_K_nd(fam, X, X0, hyp)
     assert gram_close(K, Ko)
@@ -609,7 +612,7 @@ def test_build_k_nd_vs_oracle(ops, oracle, fam, d, n, n0):
         assert gram_close(K, K1)
 
 
-@pytest.mark.parametrize("fam,d,N", [("A", 2, 300), ("C", 2, 260), ("C", 3, 200), ("A", 1, 150)])
+@pytest.mark.parametrize("fam,d,N", [("A", 2, 300), ("C", 2, 260), ("C", 3, 200), ("A", 1, 150), ("D", 2, 220), ("B", 2, 180)])
 def test_fit_pairs_vs_oracle(oracle, fam, d, N):
     from sympgpr_amd.fit import SympFit
     rng = np.random.default_rng(7 * d + N)
@@ -617,6 +620,8 @@ def test_fit_pairs_vs_oracle(oracle, fam, d, N):
     z = rng.standard_normal(2 * d * N)
     l = 1.2 * (12 * np.pi / N) ** (1.0 / (2 * d))
     hyp = np.append(np.full(2 * d, l), 1.0)
+    if fam == "D":
+        hyp = np.concatenate((hyp[:-1], np.full(d, 0.5), hyp[-1:]))
     s2 = 1e-2 / l**2
     a_o, nll_o, _ = oracle.fit_nd(fam, X, z, hyp, s2)
     with SympFit.pairs(fam, X, z, hyp, s2) as f:

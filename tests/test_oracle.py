@@ -123,13 +123,14 @@ def test_multi_rhs_solve(oracle, fits):
 
 def test_length_scale_derivative_kernels_vs_reference_fortran(oracle):
     """the eight d../dl functions build_dK / build_dKreg use (kernels.f90:135-231,
-    kernels_sq.f90:124-217), restated in the oracle, against the reference's compiled Fortran."""
+    kernels_sq.f90:124-217, kernels_sum.f90:120-208), restated in the oracle, against the reference's
+    compiled Fortran."""
     from oracle.oracle import Ref, DL_NAMES
     if not Ref.available():
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
     ref = Ref()
     rng = np.random.default_rng(3)
-    for fam in "AC":
+    for fam in "ABC":
         for _ in range(100):
             a = rng.uniform(-3, 3, 4)
             lx, ly = rng.uniform(0.3, 2, 2)
@@ -146,7 +147,7 @@ def test_nll_grad_is_the_gradient(oracle):
     x = np.hstack((rng.uniform(0, 2 * np.pi, Np), rng.uniform(-2, 2, Np)))
     y = rng.standard_normal(2 * Np)
     hyp = np.array([0.9, 1.1, 0.7, 1e-2])
-    for fam in "AC":
+    for fam in "ABC":
         val, g = oracle.nll_grad(fam, hyp, x, y, 2 * Np)
         for i in (0, 1):
             h = 1e-6
@@ -167,34 +168,47 @@ def test_build_K_nd_reduces_to_build_K_for_one_pair(oracle, gram):
         assert np.abs(K - g("K")).max() <= 4e-16 * np.abs(g("K")).max()
 
 
-@pytest.mark.parametrize("fam,d", [("A", 2), ("C", 2), ("A", 3)])
+@pytest.mark.parametrize("fam,d", [("A", 2), ("C", 2), ("A", 3), ("B", 2), ("D", 2), ("D", 1), ("B", 1)])
 def test_build_K_nd_against_sympy(oracle, fam, d):
     """d > 1 is not in the reference: the oracle is pinned on a symbolic differentiation of the
-    product kernel, the technique of the reference's own generator (01_pendulum/implicit/
-    init_func.py:24-52: define k, differentiate, evaluate)."""
+    kernel, the technique of the reference's own generator (01_pendulum/implicit/
+    init_func.py:24-52: define k, differentiate, evaluate).  A, C, D: product of the per-coordinate
+    factors (D with a free period per q); B: their sum."""
     import sympy as sp
     D = 2 * d
     xa = sp.symbols("xa0:%d" % D)
     xb = sp.symbols("xb0:%d" % D)
     ls = sp.symbols("l0:%d" % D, positive=True)
-    k = 1
+    ps = sp.symbols("p0:%d" % d, positive=True)
+    fac = []
     for m in range(D):
-        if m < d and fam == "A":
-            k *= sp.exp(-sp.sin((xa[m] - xb[m]) / 2) ** 2 / (2 * ls[m] ** 2))
+        if m < d and fam in "AB":
+            fac.append(sp.exp(-sp.sin((xa[m] - xb[m]) / 2) ** 2 / (2 * ls[m] ** 2)))
+        elif m < d and fam == "D":
+            fac.append(sp.exp(-sp.sin(ps[m] * (xa[m] - xb[m])) ** 2 / (2 * ls[m] ** 2)))
         else:
-            k *= sp.exp(-(xa[m] - xb[m]) ** 2 / (2 * ls[m] ** 2))
-    H = [[sp.lambdify(xa + xb + ls, sp.diff(k, xa[a], xb[b]), "mpmath") for b in range(D)] for a in range(D)]
+            fac.append(sp.exp(-(xa[m] - xb[m]) ** 2 / (2 * ls[m] ** 2)))
+    k = sum(fac) if fam == "B" else sp.prod(fac)
+    args = xa + xb + ls + (ps if fam == "D" else ())
+    H = [[sp.lambdify(args, sp.diff(k, xa[a], xb[b]), "mpmath") for b in range(D)] for a in range(D)]
     rng = np.random.default_rng(100 * d + ord(fam))
     n, n0 = 3, 2
     X = rng.uniform(-1.5, 1.5, (n, D)); X0 = rng.uniform(-1.5, 1.5, (n0, D))
     l = rng.uniform(0.6, 1.4, D); sig = 0.7
-    K = oracle.build_K_nd(fam, X, X0, np.append(l, sig))
+    pv = rng.uniform(0.4, 0.9, d)
+    hyp = np.concatenate((l, pv, [sig])) if fam == "D" else np.append(l, sig)
+    K = oracle.build_K_nd(fam, X, X0, hyp)
+    extra = tuple(pv) if fam == "D" else ()
     for a in range(D):
         for b in range(D):
             for i in range(n):
                 for j in range(n0):
-                    ref = sig * float(H[a][b](*X0[j], *X[i], *l))   # a = column ("0") point, as in build_K
+                    ref = sig * float(H[a][b](*X0[j], *X[i], *l, *extra))   # a = column ("0") point, as in build_K
                     assert K[a * n + i, b * n0 + j] == pytest.approx(ref, rel=1e-12, abs=1e-14)
+    if d == 1:   # one pair: the family's own build_K (restated generated Fortran)
+        hyp1 = [l[0], l[1], pv[0], sig] if fam == "D" else [l[0], l[1], sig]
+        K1 = oracle.build_K(fam, X[:, 0], X[:, 1], X0[:, 0], X0[:, 1], hyp1)
+        assert np.abs(K - K1).max() <= 1e-14 * np.abs(K1).max()
 
 
 @pytest.mark.parametrize("fam", "ABCD")
@@ -215,6 +229,6 @@ def test_all_generated_scalars_vs_reference_fixture(oracle, golden_dir, fam):
             assert close(oracle.scalar(fam, w, *pt, p), g["values"][name][i]), name
         for w, name in X_NAMES.items():
             assert close(oracle.scalar_x(fam, w, *pt, p), g["values"][name][i]), name
-        if fam in "AC":
+        if fam in "ABC":
             for w, name in DL_NAMES.items():
                 assert close(oracle.scalar_dl(fam, w, *pt), g["values"][name][i]), name
