@@ -17,23 +17,23 @@ f.run()
 f.build()
 L.check(lib.sgpr_profile_begin())
 f.factor()
-o = np.zeros(8)
+o = np.zeros(12)
 L.check(lib.sgpr_profile_end(L.dptr(o)))
 n = lib.sgpr_profile_launches(None, 0)
-buf = np.zeros(6 * n)
+buf = np.zeros(7 * n)
 lib.sgpr_profile_launches(L.dptr(buf), n)
-r = buf.reshape(n, 6)
+r = buf.reshape(n, 7)
 print("factor ms", f.stage_ms()[1], "launches", n, "sum gemm ms", r[:, 5].sum())
 from collections import defaultdict
 agg = defaultdict(lambda: [0, 0.0, 0.0])
-for m, nn, k, lower, big, ms in r:
-    key = (int(k), int(lower), int(big), "m<=1k" if m <= 1024 else ("m<=4k" if m <= 4096 else "m>4k"))
+for m, nn, k, lower, big, ms, ovl in r:
+    key = (int(k), int(lower), int(big), int(ovl), "m<=1k" if m <= 1024 else ("m<=4k" if m <= 4096 else "m>4k"))
     nl = min(m, nn)
     flop = 2 * k * ((nl * m - nl * (nl - 1) / 2) if lower else m * nn)
     a = agg[key]; a[0] += 1; a[1] += ms; a[2] += flop
 for key in sorted(agg, key=lambda k: -agg[k][1]):
     c, ms, fl = agg[key]
-    print("k=%5d lower=%d big=%d %-6s: %4d launches %8.2f ms (%5.1f us each) %6.2f TFLOP/s" % (*key, c, ms, 1e3 * ms / c, fl / ms / 1e9))
+    print("k=%5d lower=%d big=%d beside-panel-stream=%d %-6s: %4d launches %8.2f ms (%5.1f us each) %6.2f TFLOP/s" % (*key, c, ms, 1e3 * ms / c, fl / ms / 1e9))
 
 if json_out:
     big = r[r[:, 4] == 1]
