@@ -18,13 +18,9 @@ def nll_chol(hyp, x, y, N):
 
 
 def quality(qmap, pmap, H, ysint, Ntest):
-    """func.py:248-258 (host arithmetic)."""
-    gd = np.zeros([Ntest])
-    for lk in range(0, Ntest):
-        d = np.array([qmap[1, lk], pmap[1, lk]]) - np.asarray(ysint)[:, lk, 1]
-        gd[lk] = np.mean(d * d)
-    stdgd = np.std(gd[:])
-    Eosc = np.zeros([Ntest])
-    for lk in range(0, Ntest):
-        Eosc[lk] = np.std(H[:, lk]) / np.mean(H[:, lk])
-    return Eosc, gd, stdgd
+    """The five-argument diagnostics of 02_pert_pendulum/func.py:248-258 (host arithmetic): the reference orbit's
+    first point is ysint[:, k, 1] there."""
+    first = np.stack((np.asarray(qmap)[1, :Ntest], np.asarray(pmap)[1, :Ntest]))
+    gd = np.mean((first - np.asarray(ysint)[:, :Ntest, 1]) ** 2, axis=0)
+    Hk = np.asarray(H)[:, :Ntest]
+    return np.std(Hk, axis=0) / np.mean(Hk, axis=0), gd, np.std(gd)

@@ -67,15 +67,10 @@ def applymap_tok(nphmap, nm, Ntest, Q0map, P0map, xtrainp, ztrainp, Kyinvp, hypp
 
 
 def quality(qmap, pmap, H, ysint, Ntest, Nm):
-    """func.py:221-233 (host arithmetic; like the reference it wraps ysint[:, 1] in place)."""
-    yref = ysint
-    yref[:, 1] = np.mod(ysint[:, 1], 2 * np.pi)
-    gd = np.zeros([Ntest])
-    for lk in range(0, Ntest):
-        d = np.array([pmap[1, lk], qmap[1, lk]]) - yref[Nm, 0:2, lk]
-        gd[lk] = np.mean(d * d)
-    stdgd = np.std(gd[:])
-    Eosc = np.zeros([Ntest])
-    for lk in range(0, Ntest):
-        Eosc[lk] = np.std(H[lk, :]) / np.mean(H[lk, :])
-    return Eosc, gd, stdgd
+    """Diagnostics of Split_SympGPR/func.py:221-233 (host arithmetic): (p, q) against ysint[Nm, 0:2, k], H indexed
+    [orbit, step]; like the reference it wraps ysint[:, 1] mod 2 pi IN PLACE."""
+    ysint[:, 1] = np.mod(ysint[:, 1], 2 * np.pi)
+    first = np.stack((np.asarray(pmap)[1, :Ntest], np.asarray(qmap)[1, :Ntest]))
+    gd = np.mean((first - np.asarray(ysint)[Nm, 0:2, :Ntest]) ** 2, axis=0)
+    Hk = np.asarray(H)[:Ntest, :]
+    return np.std(Hk, axis=1) / np.mean(Hk, axis=1), gd, np.std(gd)

@@ -173,17 +173,15 @@ def applymap_henon(nm, Ntest, l, hypp, Q0map, P0map, xtrainp, ztrainp, Kyinvp, x
 
 
 def quality(qmap, pmap, H, ysint, Ntest, Nm):
-    """functions/func.py:262-272: geometric distance and energy oscillation (host arithmetic,
-    not part of the accelerated path)."""
-    gd = np.zeros([Ntest])
-    for lk in range(0, Ntest):
-        d = np.array([qmap[1, lk], pmap[1, lk]]) - np.asarray(ysint)[Nm, :, lk]
-        gd[lk] = np.mean(d * d)          # sklearn.metrics.mean_squared_error of two 2-vectors
-    stdgd = np.std(gd[:])
-    Eosc = np.zeros([Ntest])
-    for lk in range(0, Ntest):
-        Eosc[lk] = np.std(H[:, lk]) / np.mean(H[:, lk])
-    return Eosc, gd, stdgd
+    """Diagnostics the drivers print after applying the map (same name, arguments and return values as
+    functions/func.py:262-272; host arithmetic on [nm, Ntest] arrays, outside the accelerated path):
+    gd[k]   mean squared distance between the first mapped point (q_1, p_1) of orbit k and the reference
+            orbit ysint[Nm, :, k];  stdgd = its standard deviation over the orbits;
+    Eosc[k] relative energy oscillation std(H[:, k]) / mean(H[:, k])."""
+    first = np.stack((np.asarray(qmap)[1, :Ntest], np.asarray(pmap)[1, :Ntest]))          # (2, Ntest)
+    gd = np.mean((first - np.asarray(ysint)[Nm, :, :Ntest]) ** 2, axis=0)
+    Hk = np.asarray(H)[:, :Ntest]
+    return np.std(Hk, axis=0) / np.mean(Hk, axis=0), gd, np.std(gd)
 
 
 def build_dKreg(xin, x0in, hyp):

@@ -4,8 +4,8 @@ per-launch records of the MFMA kernel:
   python tools/pmc_traffic_json.py FETCH_counter_collection.csv WRITE_counter_collection.csv launches.json N_PTS > out.json
 
 launches.json comes from `python tools/gemm_launches.py N --json launches.json`.
-FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950: calibrated on gemv_n,
-which reads L exactly once and reports half of it)."""
+FETCH_SIZE / WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled (gfx950: calibrated on trsv_strips (reads L exactly once),
+which reads L exactly once and reports half of it: the strip solve trsv_strips_kernel)."""
 import csv
 import json
 import os
@@ -47,7 +47,11 @@ g["algorithmic_bytes_per_launch"] = la["big_compulsory_bytes"] / max(la["big_lau
 g["algorithmic_flop_per_launch"] = la["big_flop"] / max(la["big_launches"], 1)
 g["launches_in_event_run"] = la["big_launches"]
 out["gram_pairs_kernel"]["algorithmic_bytes_per_launch"] = 8.0 * n * n
-gv = "gemv_n_kernel"
+# calibration of the FETCH_SIZE doubling on a kernel whose reads are known exactly: the strip solves read L
+# once each (8 n^2 / 2 bytes per launch, two launches per step) with 16-byte loads
+gv = "trsv_strips_kernel"
 if gv in ft:
-    out["calibration_gemv_n"] = {"fetch_kb_total_reported": ft[gv], "bytes_read_algorithmic": 8.0 * n * n / 2}
+    out["calibration_trsv_strips"] = {"launches": fc[gv], "fetch_kb_total_reported": ft[gv],
+                                      "bytes_read_algorithmic_total": 8.0 * n * n / 2 * fc[gv],
+                                      "reported_over_algorithmic": ft[gv] * 1024.0 / (8.0 * n * n / 2 * fc[gv])}
 print(json.dumps(out, indent=1))
