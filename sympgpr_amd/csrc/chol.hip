@@ -183,8 +183,8 @@ __global__ __launch_bounds__(MV_T) void trsv_block_kernel(int n, const double *L
 // Forward progress does not rely on co-residency of the grid: strip ownership follows the ARRIVAL
 // order of the workgroups (a ticket), so every flag a workgroup waits for is set by a workgroup that
 // started before it.  Every spin is bounded; a timeout is reported through *dinfo (PANEL_TIMEOUT).
-constexpr int PW_MAX = 8;                       // leaf columns per panel (nb <= 1024)
-constexpr int PFLAG_STRIDE = 2 + PW_MAX + PW_MAX * PW_MAX + 6;   // ints of flag state per panel (80)
+constexpr int PW_MAX = 16;                      // leaf columns per panel (nb <= 2048)
+constexpr int PFLAG_STRIDE = 2 + PW_MAX + PW_MAX * PW_MAX + 6;   // ints of flag state per panel (280)
 constexpr int PANEL_TIMEOUT = POTRF_HANDOFF_TIMEOUT;   // *dinfo value: a hand-off was never published
 constexpr int PANEL_G_MAX = 256;                // workgroups (each holds a whole CU: 133 KiB of LDS)
 
@@ -459,7 +459,9 @@ inline size_t flag_bytes(int n)
 
 }  // namespace
 
-size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + flag_bytes(n) + 256; }
+// [ leaf inverses | hand-off words | two n-vectors the strip solves publish their segments through ]
+inline size_t pub_bytes(int n) { return ((size_t)2 * n * sizeof(double) + 255) / 256 * 256; }
+size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + flag_bytes(n) + pub_bytes(n) + 256; }
 
 namespace {
 
@@ -536,17 +538,21 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
     const bool fused_cap = pmode == 3 && c.flags && n % LEAF == 0 && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0) &&
                            off0 % LEAF == 0;
     // Block schedule.  nb > 0: uniform width (the caller's choice).  nb == 0: widths follow the order of
-    // what is left: wide blocks (k = 1024 products run at ~61 TFLOP/s, k = 512 at ~52) while the trailing
+    // what is left: wide blocks (alone, k = 2048 / 1024 / 512 products run at 61 / 57 / 49 TFLOP/s) while the trailing
     // update is what each step waits for, narrower ones once the chain of leaves is (the chain costs the
     // same per column at any width, and a narrow step loses less to its own update of block column k+1).
     std::vector<int> starts;
     {
+        // 2048-wide steps (k = 2048 updates: 61 TFLOP/s) pay off only when the early updates are long enough to
+        // hide a 16-leaf chain: measured n = 32768 198.5 -> 194.0 ms, 49152 620 -> 603, but 16384 34.0 -> 35.6
+        static const int t0_env = [] { const char *e = getenv("SGPR_LA_T0"); return e ? atoi(e) : 0; }();
+        const int t0 = t0_env > 0 ? t0_env : (n >= 24576 ? 12288 : 1 << 30);
         static const int t1 = [] { const char *e = getenv("SGPR_LA_T1"); return e ? atoi(e) : 9216; }();
         static const int t2 = [] { const char *e = getenv("SGPR_LA_T2"); return e ? atoi(e) : 2048; }();
         for (int pos = 0; pos < n;) {
             starts.push_back(pos);
             const int rem = n - pos;
-            int w = nb > 0 ? nb : (rem > t1 ? 1024 : (rem > t2 ? 512 : 256));
+            int w = nb > 0 ? nb : (rem > t0 ? 2048 : (rem > t1 ? 1024 : (rem > t2 ? 512 : 256)));
             if (nb == 0 && !fused_cap) w = la_block(n);
             pos += std::min(w, rem);
         }
@@ -715,6 +721,10 @@ static int *solve_state(int n, const void *work)
 {
     return reinterpret_cast<int *>(const_cast<char *>(static_cast<const char *>(work)) + inv_bytes(n));
 }
+static double *solve_pub(int n, const void *work)
+{
+    return reinterpret_cast<double *>(const_cast<char *>(static_cast<const char *>(work)) + inv_bytes(n) + flag_bytes(n));
+}
 
 int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st)
 {
@@ -722,10 +732,12 @@ int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, h
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
     if (use_strips(n, L, ldl)) {
         int *state = solve_state(n, work);
+        double *pub = solve_pub(n, work);
         SGPR_HIP(hipMemsetAsync(state, 0, 8 * sizeof(int), st));
-        int rc = trsv_strips(n, L, ldl, c.inv, b, 0, state, st);
+        SGPR_HIP(hipMemsetAsync(pub, 0xFF, (size_t)2 * n * sizeof(double), st));
+        int rc = trsv_strips(n, L, ldl, c.inv, b, 0, state, pub, st);
         if (rc) return rc;
-        return trsv_strips(n, L, ldl, c.inv, b, 1, state + 4, st);
+        return trsv_strips(n, L, ldl, c.inv, b, 1, state + 4, pub + n, st);
     }
     int rc = trsv_n_rec(n, L, ldl, b, 0, c);
     if (rc) return rc;
@@ -759,8 +771,10 @@ int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int tr
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
     if (use_strips(n, L, ldl)) {
         int *state = solve_state(n, work);
+        double *pub = solve_pub(n, work);
         SGPR_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int), st));
-        return trsv_strips(n, L, ldl, c.inv, b, trans, state, st);
+        SGPR_HIP(hipMemsetAsync(pub, 0xFF, (size_t)n * sizeof(double), st));
+        return trsv_strips(n, L, ldl, c.inv, b, trans, state, pub, st);
     }
     return trans ? trsv_t_rec(n, L, ldl, b, 0, c) : trsv_n_rec(n, L, ldl, b, 0, c);
 }

@@ -107,7 +107,7 @@ int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hi
 // ---- trsv.hip : one-right-hand-side triangular solve as one launch (strips + progress counter)
 bool trsv_strips_ok(int n, const double *L, size_t ldl);
 int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state /* 4 ints, zero */,
-                hipStream_t st);
+                double *pub /* n doubles, all bytes 0xFF */, hipStream_t st);
 
 // ---- batch.hip : many small fits (order <= 256 each) in one launch, one workgroup per problem
 int fit_batch_max_order();

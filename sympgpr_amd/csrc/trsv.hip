@@ -15,10 +15,13 @@
 // Strips are handed out in dependency order by a ticket (a workgroup that waits always waits for one that
 // started earlier, whatever the residency), finished strips advance `ready` (strip s done <=> all strips
 // before it in ticket order done), and a workgroup only polls when it has caught up with the frontier.
-// Hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility, "Valid forms"): the solved segment is
-// stored with agent-scope (sc1, write-through) 8-byte stores, every storing wave drains vmcnt, workgroup
-// barrier, one lane stores the counter (sc1); consumers poll the counter with sc1 loads from one lane,
-// barrier, and read the segment with sc1 loads only -- no fences, L2s are never relied on for coherence.
+// Hand-off form (MI355X_MICROARCH.md, inter-workgroup visibility, "Valid forms", 8-byte granules): the
+// solved segment IS the flag.  It is published into a side buffer `pub` that the host pre-fills with a
+// sentinel bit pattern (all ones: a NaN no arithmetic produces; a NaN result is canonicalised before it is
+// published), with agent-scope (sc1, write-through) 8-byte stores by ONE wave; the 128 lanes of the consumer
+// that carry the segment re-load their own element (sc1) until it is no longer the sentinel -- no flag,
+// no fence, no drain between data and signal on the chain of strips.  The progress counter (written behind
+// a drain, off that chain) only tells later strips how far they may read without polling.
 // L itself and the leaf inverses are read-only here: plain 16-byte loads.
 #include "common.h"
 
@@ -39,6 +42,7 @@ struct TrsvArgs {
     size_t ldl;
     const double *inv;     // leaf inverses, LEAF x LEAF each
     double *b;             // right-hand side in, solution out
+    double *pub;           // n doubles, all-ones on entry: the solved segments as the strips publish them
     int *state;            // [0] ticket, [1] ready (strips finished, in ticket order), [2] timeout flag
     int trans;
 };
@@ -50,6 +54,12 @@ __device__ __forceinline__ void store_sc1(double *p, double v)
 __device__ __forceinline__ double load_sc1(const double *p)
 {
     return __longlong_as_double((long long)__hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+constexpr unsigned long long UNPUBLISHED = ~0ull;
+__device__ __forceinline__ void publish(double *p, double v)
+{
+    if (v != v) v = __longlong_as_double(0x7FF8000000000000ll);       // never the sentinel
+    store_sc1(p, v);
 }
 
 // one 128 x 128 tile (column-major, leading dimension ld) into registers: lane l of wave w holds rows
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
             return fwd ? a.L + (size_t)s * LEAF + (size_t)q * LEAF * a.ldl
                        : a.L + (size_t)(T - 1 - q) * LEAF + (size_t)s * LEAF * a.ldl;
         };
-        auto seg_ptr = [&](int q) { return a.b + (size_t)(fwd ? q : T - 1 - q) * LEAF; };
+        auto seg_ptr = [&](int q) { return a.pub + (size_t)(fwd ? q : T - 1 - q) * LEAF; };
         double acc_r0 = 0.0, acc_r1 = 0.0;                    // forward: sums of this lane's two rows
         double acc_c[TS_CPW];                                 // backward: sums of this wave's 16 columns
 #pragma unroll
@@ -106,20 +116,21 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
             if (q >= known) {
                 if (tid < LEAF) {
                     unsigned spins = 0;
-                    int r;
-                    while ((r = __hip_atomic_load((gi32 *)(a.state + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= q) {
+                    unsigned long long bits;
+                    gu64 *src = (gu64 *)(seg_ptr(q) + tid);
+                    while ((bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == UNPUBLISHED) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (20u << 20)) { r = -1; break; }       // ~ seconds: give up
+                        if (++spins > (20u << 20)) break;                    // ~ seconds: give up
                     }
-                    vec[q & 1][tid] = r < 0 ? 0.0 : load_sc1(seg_ptr(q) + tid);
-                    if (tid == 0) {
-                        if (r < 0) __hip_atomic_store((gi32 *)(a.state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sh[2 + (q & 1)] = r;
-                    }
+                    vec[q & 1][tid] = __longlong_as_double((long long)bits);
+                    if (bits == UNPUBLISHED) __hip_atomic_store((gi32 *)(a.state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0)   // how far the others are: later segments up to there need no polling
+                        sh[2 + (q & 1)] = bits == UNPUBLISHED ? -1 : __hip_atomic_load((gi32 *)(a.state + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
-                known = sh[2 + (q & 1)];
-                if (known < 0) return;
+                const int r = sh[2 + (q & 1)];
+                if (r < 0) return;
+                known = r > q + 1 ? r : q + 1;
             } else {
                 const double seg = have_next ? seg_next : (tid < LEAF ? load_sc1(seg_ptr(q) + tid) : 0.0);
                 if (tid < LEAF) vec[q & 1][tid] = seg;
@@ -173,8 +184,11 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
                 double y0 = 0.0, y1 = 0.0;
 #pragma unroll
                 for (int w = 0; w < TS_W; ++w) { y0 += red2[w][2 * lane]; y1 += red2[w][2 * lane + 1]; }
-                store_sc1(bs + 2 * lane, y0);
-                store_sc1(bs + 2 * lane + 1, y1);
+                double *ps = a.pub + (size_t)s * LEAF;
+                publish(ps + 2 * lane, y0);
+                publish(ps + 2 * lane + 1, y1);
+                bs[2 * lane] = y0;
+                bs[2 * lane + 1] = y1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store((gi32 *)(a.state + 1), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -202,8 +216,12 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
             }
             __syncthreads();
             if (wave == 0) {
-                store_sc1(bs + 2 * lane, red2[0][2 * lane]);
-                store_sc1(bs + 2 * lane + 1, red2[0][2 * lane + 1]);
+                double *ps = a.pub + (size_t)s * LEAF;
+                const double x0 = red2[0][2 * lane], x1 = red2[0][2 * lane + 1];
+                publish(ps + 2 * lane, x0);
+                publish(ps + 2 * lane + 1, x1);
+                bs[2 * lane] = x0;
+                bs[2 * lane + 1] = x1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store((gi32 *)(a.state + 1), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -221,13 +239,14 @@ bool trsv_strips_ok(int n, const double *L, size_t ldl)
 }
 
 // b (n) := L^-1 b (trans = 0) or L^-T b, n a multiple of 128, L 16-byte aligned with an even leading
-// dimension; `state`: 4 ints of device scratch, ZERO on entry (ticket, progress counter, timeout mark).
-// One launch.
-int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state, hipStream_t st)
+// dimension; `state`: 4 ints of device scratch, ZERO on entry (ticket, progress counter, timeout mark);
+// `pub`: n doubles of device scratch, every byte 0xFF on entry.  One launch.
+int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state, double *pub,
+                hipStream_t st)
 {
     if (n <= 0) return 0;
     if (!trsv_strips_ok(n, L, ldl)) { set_error("trsv_strips: shape not supported"); return SGPR_E_ARG; }
-    TrsvArgs a{n / LEAF, L, ldl, inv, b, state, trans};
+    TrsvArgs a{n / LEAF, L, ldl, inv, b, pub, state, trans};
     const int grid = a.T < 256 ? a.T : 256;
     hipLaunchKernelGGL(trsv_strips_kernel, dim3(grid), dim3(TS_T), 0, st, a);
     SGPR_CHECK_LAUNCH();
