@@ -695,7 +695,10 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     // factorisation, recursive above (measured crossover; SGPR_POTRF=rec|la overrides)
     static const int mode = [] { const char *e = getenv("SGPR_POTRF"); return !e ? 0 : (e[0] == 'r' ? 1 : 2); }();
     static const int nb_env = [] { const char *e = getenv("SGPR_POTRF_NB"); return e ? atoi(e) : 0; }();
-    Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : 57344, flags};
+    // blocks of order <= la_max go to the blocked look-ahead driver, larger ones split recursively
+    // (SGPR_LA_MAX overrides; measured crossover of round 1)
+    static const int la_max_env = [] { const char *e = getenv("SGPR_LA_MAX"); return e ? atoi(e) : 57344; }();
+    Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : la_max_env, flags};
     if (mode == 2 || (nb_env > 0 && mode == 0 && n > 4 * LEAF && n <= c.la_max))
         return potrf_lookahead(n, A, lda, c, nb_env > 0 ? nb_env : 0, 0);
     return potrf_rec(n, A, lda, 0, c);

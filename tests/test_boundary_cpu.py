@@ -128,3 +128,65 @@ int main(){ std::mt19937_64 g(1); std::uniform_real_distribution<double> ux(-745
                         os.path.join(td, "t.cpp"), "-o", exe], check=True)
         me, ms, mc = map(float, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
     assert me < 4e-16 and ms < 1.5e-16 and mc < 1.5e-16
+
+
+def _probe_header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sympgpr_probe.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sgpr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_probe_library_is_separate_and_complete():
+    """measurement aids live in libsympgpr_probe.so / include/sympgpr_probe.h: every declared symbol is
+    exported there, bound in _lib.PROBE_SIGNATURES, and NOT part of the product header"""
+    import ctypes
+    from sympgpr_amd import _lib
+    probe = ctypes.CDLL(os.path.join(os.path.dirname(_lib.lib_path()), "libsympgpr_probe.so"))
+    syms = _probe_header_symbols()
+    assert syms and sorted(_lib.PROBE_SIGNATURES) == syms
+    for s in syms:
+        assert hasattr(probe, s), "libsympgpr_probe.so does not export " + s
+    assert not any(s.startswith("sgpr_probe") for s in _header_symbols())
+
+
+def test_generated_kernels_are_up_to_date(tmp_path, monkeypatch):
+    """tools/gen_kernels.py (sympy -> HIP, the device-side counterpart of the reference's init_func.py)
+    reproduces the committed csrc/generated/pair_generated.h byte for byte"""
+    pytest.importorskip("sympy")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_kernels", os.path.join(ROOT, "tools", "gen_kernels.py"))
+    gk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gk)
+    out = tmp_path / "pair_generated.h"
+    monkeypatch.setattr(gk, "OUT", str(out))
+    gk.main()
+    committed = open(os.path.join(ROOT, "sympgpr_amd", "csrc", "generated", "pair_generated.h")).read()
+    assert out.read_text() == committed
+
+
+def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
+    """`python bench.py --gpus N` typed by hand: the parent only spawns `torch.distributed.run` children
+    (no HIP call, no exec of a process that has initialised the GPU)"""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd):
+        seen["cmd"] = cmd
+        return 7
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    before = set(sys.modules)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert "sympgpr_amd._lib" not in set(sys.modules) - before      # the product library was not even loaded
