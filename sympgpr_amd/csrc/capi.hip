@@ -69,6 +69,17 @@ struct sgpr_fit {
     bool timed[3] = {false, false, false};
 };
 
+// the strip solves bound their spins; a give-up is reported at the first call that waits for the solve
+static int check_solve(sgpr_fit_t f)
+{
+    if (!trsv_uses_strips(f->n, f->dA, (size_t)f->n)) return 0;
+    int h[8] = {};
+    SGPR_HIP(hipMemcpyAsync(h, trsv_state(f->n, f->work), sizeof(h), hipMemcpyDeviceToHost, f->st));
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    if (h[2] || h[6]) { set_error("triangular solve: a hand-off between strips timed out"); return SGPR_E_HIP; }
+    return 0;
+}
+
 extern "C" {
 
 int sgpr_abi_version(void) { return SGPR_ABI_VERSION; }
@@ -558,7 +569,7 @@ int sgpr_fit_alpha(sgpr_fit_t f, double *alpha_out)
     if (!f->solved) { set_error("fit_alpha: not solved"); return SGPR_E_STATE; }
     SGPR_HIP(hipMemcpyAsync(alpha_out, f->dalpha, (size_t)f->n * sizeof(double), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
-    return 0;
+    return check_solve(f);
 }
 
 int sgpr_fit_nll(sgpr_fit_t f, double *nll_out)
@@ -567,7 +578,7 @@ int sgpr_fit_nll(sgpr_fit_t f, double *nll_out)
     if (!f->solved) { set_error("fit_nll: not solved"); return SGPR_E_STATE; }
     SGPR_HIP(hipMemcpyAsync(nll_out, f->dscal, sizeof(double), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
-    return 0;
+    return check_solve(f);
 }
 
 int sgpr_fit_ldiag(sgpr_fit_t f, double *diag_out)

@@ -547,7 +547,7 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
         // hide a 16-leaf chain: measured n = 32768 198.5 -> 194.0 ms, 49152 620 -> 603, but 16384 34.0 -> 35.6
         static const int t0_env = [] { const char *e = getenv("SGPR_LA_T0"); return e ? atoi(e) : 0; }();
         const int t0 = t0_env > 0 ? t0_env : (n >= 24576 ? 12288 : 1 << 30);
-        static const int t1 = [] { const char *e = getenv("SGPR_LA_T1"); return e ? atoi(e) : 9216; }();
+        static const int t1 = [] { const char *e = getenv("SGPR_LA_T1"); return e ? atoi(e) : 6144; }();   // swept 2048 .. 9216: n = 12288 18.7 -> 18.1 ms, 16384 34.2 -> 33.4
         static const int t2 = [] { const char *e = getenv("SGPR_LA_T2"); return e ? atoi(e) : 2048; }();
         for (int pos = 0; pos < n;) {
             starts.push_back(pos);
@@ -728,6 +728,12 @@ static double *solve_pub(int n, const void *work)
 {
     return reinterpret_cast<double *>(const_cast<char *>(static_cast<const char *>(work)) + inv_bytes(n) + flag_bytes(n));
 }
+
+// After a potrs_vec / trsv on this workspace has been waited for: did a strip kernel give up on a hand-off
+// (a bounded spin ran out: a bug or a device problem, never a property of the matrix)?  `host8` = the 8 state
+// words copied back by the caller (null when the strip kernels were not used for this order).
+bool trsv_uses_strips(int n, const double *L, size_t ldl) { return use_strips(n, L, ldl); }
+const int *trsv_state(int n, const void *work) { return solve_state(n, work); }
 
 int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st)
 {

@@ -101,6 +101,8 @@ int trsm_rl(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, co
 int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, size_t ldb, int nrhs, double *scratch,
               hipStream_t st);  // B (n x nrhs) := L^-T L^-1 B; scratch: nrhs x n doubles
 int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st);
+bool trsv_uses_strips(int n, const double *L, size_t ldl);      // potrs_vec / trsv take the one-launch strip kernels
+const int *trsv_state(int n, const void *work);                 // their 8 state words: [2], [6] != 0 = a hand-off timed out
 int leaf_probe(double *A, size_t lda, double *inv, int *dinfo, unsigned long long *stamps, hipStream_t st);
 int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hipStream_t st);
 
