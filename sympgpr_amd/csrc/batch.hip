@@ -13,7 +13,7 @@
 // L22 = leaf(A22);  y = L^-1 z and alpha = L^-T y through the leaf inverses.  Latency-bound by
 // construction: throughput comes from the number of problems in flight, not from the matrix cores.
 #include <cmath>
-#include <vector>
+#include <cstring>
 
 #include "common.h"
 #include "leaf.h"
@@ -171,12 +171,44 @@ __global__ __launch_bounds__(LT) void fit_batch_kernel(const BatchArgs a)
     }
 }
 
-struct Buf {
-    void *p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { SGPR_HIP(hipMalloc(&p, bytes ? bytes : 8)); return 0; }
-    template <typename T> T *as() { return static_cast<T *>(p); }
+// Device + pinned-host staging of one calling thread, grown on demand and kept: a call is then one H2D copy,
+// one launch and one D2H copy (nine hipMalloc / hipFree pairs and eight small pageable copies per call were
+// most of a single small fit's 230 us through a handle).
+struct Arena {
+    char *dev = nullptr, *host = nullptr;
+    size_t cap_dev = 0, cap_host = 0;
+    int device = -1;
+    // no destructor: at thread / process exit the HIP runtime may already be gone; the OS reclaims
+    void release()
+    {
+        if (dev) (void)hipFree(dev);
+        if (host) (void)hipHostFree(host);
+        dev = host = nullptr;
+        cap_dev = cap_host = 0;
+    }
+    int reserve(size_t need_dev, size_t need_host)
+    {
+        int cur = 0;
+        SGPR_HIP(hipGetDevice(&cur));
+        if (cur != device) { release(); device = cur; }
+        if (need_dev > cap_dev) {
+            if (dev) (void)hipFree(dev);
+            dev = nullptr; cap_dev = 0;
+            SGPR_HIP(hipMalloc((void **)&dev, need_dev));
+            cap_dev = need_dev;
+        }
+        if (need_host > cap_host) {
+            if (host) (void)hipHostFree(host);
+            host = nullptr; cap_host = 0;
+            SGPR_HIP(hipHostMalloc((void **)&host, need_host, hipHostMallocDefault));
+            cap_host = need_host;
+        }
+        return 0;
+    }
 };
+thread_local Arena t_arena;
+
+inline size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 
 }  // namespace
 
@@ -194,43 +226,51 @@ int fit_batch(int family, int nbatch, int npts, const double *x, const double *y
         return SGPR_E_ARG;
     }
     if (nbatch == 0) return 0;
-    std::vector<KConst> kcs(nbatch);
-    std::vector<double> noise(nbatch);
-    for (int b = 0; b < nbatch; ++b) {
-        int rc = make_kconst(family, hyp + (size_t)b * nhyp, nhyp, &kcs[b]);
-        if (rc) return rc;
-        noise[b] = std::fabs(sig2n[b]);
-    }
+    if (family < SGPR_FAM_A || family > SGPR_FAM_D) { set_error("fit_batch: unknown kernel family"); return SGPR_E_ARG; }
+    const size_t B = (size_t)nbatch;
     const int grid = nbatch < 1024 ? nbatch : 1024;
     const size_t per_wg = (size_t)BMAX * BMAX + 2 * (size_t)LEAF * LEAF + 2 * BMAX;
-    Buf dx, dy, dz, dkc, dno, dscr, dal, dnll, dinfo;
-    int rc;
-    const size_t B = (size_t)nbatch;
-    if ((rc = dx.alloc(B * npts * 8)) || (rc = dy.alloc(B * npts * 8)) || (rc = dz.alloc(B * n * 8)) ||
-        (rc = dkc.alloc(B * sizeof(KConst))) || (rc = dno.alloc(B * 8)) || (rc = dscr.alloc((size_t)grid * per_wg * 8)) ||
-        (rc = dal.alloc(B * n * 8)) || (rc = dnll.alloc(B * 8)) || (rc = dinfo.alloc(B * sizeof(int))))
-        return rc;
+    // input block (one H2D): x | y | z | KConst | noise ; output block (one D2H): alpha | nll | info
+    const size_t o_x = 0, o_y = o_x + up256(B * npts * 8), o_z = o_y + up256(B * npts * 8), o_kc = o_z + up256(B * n * 8),
+                 o_no = o_kc + up256(B * sizeof(KConst)), in_bytes = o_no + up256(B * 8);
+    const size_t o_al = 0, o_nll = o_al + up256(B * n * 8), o_info = o_nll + up256(B * 8), out_bytes = o_info + up256(B * sizeof(int));
+    const size_t scr_bytes = (size_t)grid * per_wg * 8;
+    Arena &ar = t_arena;
+    int rc = ar.reserve(in_bytes + out_bytes + scr_bytes, in_bytes + out_bytes);
+    if (rc) return rc;
+    char *hin = ar.host, *hout = ar.host + in_bytes;
+    char *din = ar.dev, *dout = ar.dev + in_bytes, *dscr = ar.dev + in_bytes + out_bytes;
+    memcpy(hin + o_x, x, B * npts * 8);
+    memcpy(hin + o_y, y, B * npts * 8);
+    memcpy(hin + o_z, z, B * n * 8);
+    KConst *kcs = reinterpret_cast<KConst *>(hin + o_kc);
+    double *noise = reinterpret_cast<double *>(hin + o_no);
+    for (int b = 0; b < nbatch; ++b) {
+        if ((rc = make_kconst(family, hyp + (size_t)b * nhyp, nhyp, &kcs[b]))) return rc;
+        noise[b] = std::fabs(sig2n[b]);
+    }
     hipStream_t st = nullptr;
-    SGPR_HIP(hipMemcpyAsync(dx.p, x, B * npts * 8, hipMemcpyHostToDevice, st));
-    SGPR_HIP(hipMemcpyAsync(dy.p, y, B * npts * 8, hipMemcpyHostToDevice, st));
-    SGPR_HIP(hipMemcpyAsync(dz.p, z, B * n * 8, hipMemcpyHostToDevice, st));
-    SGPR_HIP(hipMemcpyAsync(dkc.p, kcs.data(), B * sizeof(KConst), hipMemcpyHostToDevice, st));
-    SGPR_HIP(hipMemcpyAsync(dno.p, noise.data(), B * 8, hipMemcpyHostToDevice, st));
-    SGPR_HIP(hipMemsetAsync(dinfo.p, 0, B * sizeof(int), st));
-    BatchArgs a{nbatch, npts, n, reg, dx.as<double>(), dy.as<double>(), dz.as<double>(), dkc.as<KConst>(),
-                dno.as<double>(), dscr.as<double>(), dal.as<double>(), dnll.as<double>(), dinfo.as<int>()};
+    SGPR_HIP(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
+    SGPR_HIP(hipMemsetAsync(dout + o_info, 0, B * sizeof(int), st));
+    BatchArgs a{nbatch, npts, n, reg, reinterpret_cast<double *>(din + o_x), reinterpret_cast<double *>(din + o_y),
+                reinterpret_cast<double *>(din + o_z), reinterpret_cast<KConst *>(din + o_kc),
+                reinterpret_cast<double *>(din + o_no), reinterpret_cast<double *>(dscr),
+                reinterpret_cast<double *>(dout + o_al), reinterpret_cast<double *>(dout + o_nll),
+                reinterpret_cast<int *>(dout + o_info)};
     switch (family) {
     case SGPR_FAM_A: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_A>, dim3(grid), dim3(LT), 0, st, a); break;
     case SGPR_FAM_B: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_B>, dim3(grid), dim3(LT), 0, st, a); break;
     case SGPR_FAM_C: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_C>, dim3(grid), dim3(LT), 0, st, a); break;
-    case SGPR_FAM_D: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_D>, dim3(grid), dim3(LT), 0, st, a); break;
-    default: set_error("fit_batch: unknown kernel family"); return SGPR_E_ARG;
+    default:         hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_D>, dim3(grid), dim3(LT), 0, st, a); break;
     }
     SGPR_CHECK_LAUNCH();
-    if (alpha) SGPR_HIP(hipMemcpyAsync(alpha, dal.p, B * n * 8, hipMemcpyDeviceToHost, st));
-    SGPR_HIP(hipMemcpyAsync(nll, dnll.p, B * 8, hipMemcpyDeviceToHost, st));
-    SGPR_HIP(hipMemcpyAsync(info, dinfo.p, B * sizeof(int), hipMemcpyDeviceToHost, st));
+    // without alpha only the tail of the output block comes back
+    const size_t from = alpha ? 0 : o_nll;
+    SGPR_HIP(hipMemcpyAsync(hout + from, dout + from, out_bytes - from, hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipStreamSynchronize(st));
+    if (alpha) memcpy(alpha, hout + o_al, B * n * 8);
+    memcpy(nll, hout + o_nll, B * 8);
+    memcpy(info, hout + o_info, B * sizeof(int));
     return 0;
 }
 

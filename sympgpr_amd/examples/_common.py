@@ -32,6 +32,16 @@ def nll_fit(family, hyp, x, y, N, reg=False, neig=None):
     x = np.asarray(x, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     npts = N if reg else N // 2
+    if 0 < N <= _base._SMALL_ORDER and (reg or N % 2 == 0):
+        # the drivers' own sizes: the whole objective in one single-workgroup launch (see func._nll_small)
+        from ..fit import fit_batch
+        _, nll, info = fit_batch(family, x[None, 0:npts], x[None, npts:2 * npts], y[None, :N], hyp[None, :-1],
+                                 np.abs(hyp[-1:]), reg=reg, want_alpha=False)
+        if not info[0]:
+            return float(nll[0])
+        if neig is None:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info[0]))
+        # not positive definite and the driver has an eigen fallback: take it through the handle below
     with SympFit(family, x[0:npts], x[npts:2 * npts], y[:N], hyp[:-1], np.abs(hyp[-1]), reg=reg,
                  lower_only=neig is None) as f:
         if neig is None:

@@ -25,6 +25,9 @@ from .ops import get_family, set_family, solve_cholesky as _solve_cholesky  # no
 from .predict import Predictor, solve_implicit_P
 
 
+_SMALL_ORDER = 256      # sgpr_fit_batch_max_order(): up to here one objective call is one single-workgroup launch
+
+
 def _l(l):
     return tuple(float(v) for v in l)
 
@@ -82,12 +85,28 @@ def solve_cholesky(L, b):
     return _solve_cholesky(L, b)
 
 
+def _nll_small(hyp, x, y, N, reg):
+    """One objective value at the drivers' own sizes (matrix order <= 256): the whole body runs in ONE launch of
+    one workgroup (sgpr_fit_batch with a batch of one) -- a device-resident handle costs five launches, an
+    allocation per buffer and 230-390 us at these orders, more than the reference's CPU path needs at order 80."""
+    from .fit import fit_batch
+    npts = N if reg else N // 2
+    _, nll, info = fit_batch(get_family(), x[None, 0:npts], x[None, npts:2 * npts], y[None, :N if reg else 2 * npts],
+                             hyp[None, :-1], np.abs(hyp[-1:]), reg=reg, want_alpha=False)
+    if info[0]:
+        raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % int(info[0]))
+    return float(nll[0])
+
+
 def nll_chol_reg(hyp, x, y, N):
     """functions/func.py:180-187: negative log-posterior of the scalar-kernel GP.  N = matrix
     order; x holds (q || p) and is sliced exactly as buildKreg does."""
     hyp = np.asarray(hyp, dtype=np.float64)
     x = np.asarray(x, dtype=np.float64)
-    with SympFit(get_family(), x[0:N], x[N:2 * N], np.asarray(y, dtype=np.float64)[:N], hyp[:-1],
+    y = np.asarray(y, dtype=np.float64)
+    if 0 < N <= _SMALL_ORDER:
+        return _nll_small(hyp, x, y, N, True)
+    with SympFit(get_family(), x[0:N], x[N:2 * N], y[:N], hyp[:-1],
                  np.abs(hyp[-1]), reg=True) as f:
         return f.run().nll()
 
@@ -97,8 +116,11 @@ def nll_chol(hyp, x, y, N):
     (twice the number of points build_K slices out of x)."""
     hyp = np.asarray(hyp, dtype=np.float64)
     x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    if 0 < N <= _SMALL_ORDER and N % 2 == 0:
+        return _nll_small(hyp, x, y, N, False)
     npts = N // 2
-    with SympFit(get_family(), x[0:npts], x[npts:2 * npts], np.asarray(y, dtype=np.float64)[:2 * npts],
+    with SympFit(get_family(), x[0:npts], x[npts:2 * npts], y[:2 * npts],
                  hyp[:-1], np.abs(hyp[-1])) as f:
         return f.run().nll()
 

@@ -1,5 +1,6 @@
 """Fits per second of the batched small-fit launch (sgpr_fit_batch) at the drivers' own sizes, beside (a) one
-nll_chol at a time through a device-resident handle and (b) the reference's CPU path for the same call
+nll_chol at a time as the unmodified drivers call it (a batch of one: one launch), (a') one device-resident handle
+per call (round 1's path) and (b) the reference's CPU path for the same call
 (its compiled Fortran build_K from oracle/_ref + the SciPy cholesky / solve_triangular of
 python/functions/func.py:189-196, one thread, as the reference runs it).
 python tools/batch_rate.py [orders...]   (default 80 160)"""
@@ -11,7 +12,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sympgpr_amd import func
-from sympgpr_amd.fit import fit_batch
+from sympgpr_amd.fit import SympFit, fit_batch
 
 
 def cpu_nll(ref, x, y, z, hyp, s2):
@@ -35,8 +36,8 @@ def main():
     ref = Ref() if Ref.available() else None
     rng = np.random.default_rng(3)
     func.set_family("A")
-    print("| order n | batch size | batched launch | one handle per call | reference CPU path (1 thread) |")
-    print("|---|---|---|---|---|")
+    print("| order n | batch size | batched launch | one call at a time (func.nll_chol) | one handle per call (SympFit) | reference CPU path (1 thread) |")
+    print("|---|---|---|---|---|---|")
     for n in orders:
         Np = n // 2
         for B in (4, 64, 1024):
@@ -54,8 +55,13 @@ def main():
             m = min(B, 64)
             t0 = time.perf_counter()
             one = [func.nll_chol(np.append(hyp[b], s2[b]), np.hstack((x[b], y[b])), z[b], n) for b in range(m)]
-            th = (time.perf_counter() - t0) / m
+            t1c = (time.perf_counter() - t0) / m
             assert np.allclose(one, nll[:m], rtol=1e-10)
+            t0 = time.perf_counter()
+            for b in range(m):
+                with SympFit("A", x[b], y[b], z[b], hyp[b], s2[b]) as f:
+                    f.run().nll()
+            th = (time.perf_counter() - t0) / m
             if ref is not None:
                 t0 = time.perf_counter()
                 cpu = [cpu_nll(ref, x[b], y[b], z[b], hyp[b], s2[b]) for b in range(m)]
@@ -64,7 +70,8 @@ def main():
                 cpu_s = "%.0f fits/s (%.0f us)" % (1 / tc, tc * 1e6)
             else:
                 cpu_s = "n/a"
-            print("| %d | %d | %.0f fits/s (%.1f us) | %.0f fits/s (%.0f us) | %s |" % (n, B, 1 / tb, tb * 1e6, 1 / th, th * 1e6, cpu_s))
+            print("| %d | %d | %.0f fits/s (%.1f us) | %.0f fits/s (%.0f us) | %.0f fits/s (%.0f us) | %s |" % (
+                n, B, 1 / tb, tb * 1e6, 1 / t1c, t1c * 1e6, 1 / th, th * 1e6, cpu_s))
 
 
 if __name__ == "__main__":
