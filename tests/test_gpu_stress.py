@@ -56,3 +56,41 @@ def test_random_sizes_fit(oracle):
         ao, nllo, _ = oracle.fit(fam, q, P, z, hyp, s2)
         assert np.linalg.norm(a - ao) <= 1e-10 * np.linalg.norm(ao), (fam, N)
         assert nll == pytest.approx(nllo, rel=1e-10), (fam, N)
+
+
+def test_two_threads_two_handles(oracle):
+    """different fit handles may be driven from different threads at once (ctypes releases the
+    GIL): per-handle workspaces and hand-off words, a thread-local error string and batch arena, the profile
+    window behind a mutex, the look-ahead side stream shared per device.  Two threads factor and solve
+    different problems concurrently, several times; every result equals the single-threaded oracle fit."""
+    import threading
+    from sympgpr_amd.fit import SympFit, fit_batch
+    rng = np.random.default_rng(77)
+    probs = []
+    for N in (1536, 2048):
+        q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+        l = 2.0 * np.sqrt(12 * np.pi / N)
+        probs.append((q, P, z, [l, l, 1.0], 1e-2 / l**2))
+    want = [oracle.fit("A", *p, threads=4)[:2] for p in probs]
+    errs = []
+
+    def work(i):
+        try:
+            q, P, z, hyp, s2 = probs[i]
+            for _ in range(4):
+                with SympFit("A", q, P, z, hyp, s2) as f:
+                    a, nll = f.run().alpha(), f.nll()
+                assert np.linalg.norm(a - want[i][0]) / np.linalg.norm(want[i][0]) < 1e-10
+                assert abs(nll - want[i][1]) <= 1e-11 * abs(want[i][1])
+                # and a small batched fit from the same thread (per-thread staging arena)
+                al, nl, info = fit_batch("A", q[None, :40], P[None, :40], z[None, :80], np.array([hyp]), s2)
+                assert info[0] == 0 and np.isfinite(nl[0])
+        except Exception as e:      # noqa: BLE001  (re-raised in the main thread)
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errs:
+        raise errs[0]
