@@ -33,6 +33,12 @@ t1 = timeit(lambda: ops.gram_pairs("A", N, N, x, y, x, y, hyp, A, [0, N, N * n, 
 t2 = timeit(lambda: ops.gram_nd("A", 1, N, N, X, X, hyp, A, n))
 for name, ts in (("gram_pairs", t1), ("gram_nd d=1", t2)):
     print("%-12s %s ms -> %.0f GB/s" % (name, ["%.2f" % t for t in ts], 8.0 * n * n / min(ts) / 1e6))
+# how much of the time is the pair arithmetic?  the same build with the device-libs exp / sincos (~110 fp64 ops
+# instead of ~50), and with families that need no sincos (C) or two exps (B)
+for fam, flags, label in (("A", L.G_ALL | L.G_OCML, "A, OCML math"), ("C", L.G_ALL, "C (exp only)"), ("B", L.G_ALL, "B (two exps)"),
+                          ("A", L.G_ALL | L.G_LOWER, "A, lower only")):
+    ts = timeit(lambda: ops.gram_pairs(fam, N, N, x, y, x, y, hyp, A, [0, N, N * n, N + N * n], n, flags))
+    print("%-16s %s ms" % (label, ["%.3f" % t for t in ts]))
 for gap in (0.001, 0.05, 0.5):
     t1 = timeit(lambda: ops.gram_pairs("A", N, N, x, y, x, y, hyp, A, [0, N, N * n, N + N * n], n, L.G_ALL), gap)
     t2 = timeit(lambda: ops.gram_nd("A", 1, N, N, X, X, hyp, A, n), gap)
