@@ -173,7 +173,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if sympgpr_amd.device_count() < max(1, min(args.gpus, world)):
+    # rehearsal hook for a one-GPU box (not a measurement): SGPR_BENCH_ONE_CARD=1 puts every rank on cuda:0 and
+    # carries the collectives over gloo, so that the whole N > 1 leg (launcher, barriers, timing reduction,
+    # per-launch pass, JSON line) can be exercised without a second GPU; at most 6 ranks share a card
+    one_card = os.environ.get("SGPR_BENCH_ONE_CARD") == "1"
+    if one_card:
+        local_rank = 0
+    if not one_card and sympgpr_amd.device_count() < max(1, min(args.gpus, world)):
         raise SystemExit("bench.py --gpus %d needs %d GPU(s), this box shows %d: libsympgpr_hip.so has no CPU fallback"
                          % (args.gpus, args.gpus, sympgpr_amd.device_count()))
     if local_rank >= sympgpr_amd.device_count():
@@ -183,7 +189,10 @@ def main():
     L.check(lib.sgpr_set_device(local_rank))
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_card:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:

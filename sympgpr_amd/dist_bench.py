@@ -112,7 +112,8 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
             "unit": "TFLOP/s (n^3/3 flop over the whole step: Gram build + Cholesky + solve)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" -- REHEARSAL: all ranks on one card, collectives over gloo (not a multi-GPU measurement)"
+                                   if dist.get_backend() == "gloo" else ""),
             "config": {"workload": "synthetic N=%d points, %s: matrix order n=%d (%.1f GB fp64) 2-D block-cyclic %dx%d, "
                                    "nb=%d, family %s" % (n_pts, "d=2 input coordinates (q,P)" if d == 1 else
                                                          "%d canonical pairs per point" % d, n, 8.0 * n * n / 1e9, pr,
