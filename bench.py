@@ -11,8 +11,13 @@ matrix order is n = 2N = 131072 (137 GB in place; see SURVEY.md 8 preamble).  `v
 whole-step Cholesky-equivalent rate (n^3/3 flop / wall time of the whole step, build and solve
 included); the per-stage rates are reported beside it.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--n-pts N] [--family A]
-        N > 1 is launched by torch.distributed.run, one rank per GPU.
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--n-pts N] [--d D] [--family A|B|C|D]
+        N > 1: one rank per GPU over RCCL.  Under `python -m torch.distributed.run ...` (the driver's launcher)
+        the ranks just join; typed by hand, `python bench.py --gpus N` starts them itself as child processes
+        before anything in the parent touches the GPU.
+        After the K timed steps ONE extra, untimed step records a HIP-event pair around every launch of the MFMA
+        kernel (roofline.achieved); roofline.traffic comes from the committed PMC passes under profiles/ when
+        their source hash matches the kernels being run.
 """
 import argparse
 import ctypes as C
