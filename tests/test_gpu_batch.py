@@ -128,3 +128,35 @@ def test_sections_use_one_launch(oracle):
         cond = 2e5
         assert np.linalg.norm(loc[m][0] - a_o) / np.linalg.norm(a_o) < 50 * cond * 2.2e-16
         assert loc[m][1] == pytest.approx(nll_o, rel=1e-10)
+
+
+def test_fit_batch_edges(oracle):
+    """empty batch; an order above the one-launch limit is refused by the C ABI and looped by nll_chol_batch;
+    a NaN target propagates to that problem only"""
+    import sympgpr_amd
+    from sympgpr_amd import func
+    from sympgpr_amd.fit import batch_max_order, fit_batch
+    assert batch_max_order() == 256
+    al, nll, info = fit_batch("A", np.zeros((0, 5)), np.zeros((0, 5)), np.zeros((0, 10)), np.zeros((0, 3)), np.zeros(0))
+    assert al.shape == (0, 10) and nll.shape == (0,) and info.shape == (0,)
+    rng = np.random.default_rng(4)
+    with pytest.raises(sympgpr_amd.SympGPRError):
+        fit_batch("A", rng.random((2, 129)), rng.random((2, 129)), rng.random((2, 258)), np.tile([0.5, 0.5, 1.0], (2, 1)), 1e-2)
+    # order 300 > 256: nll_chol_batch falls back to one handle per row
+    Np = 150
+    x = np.hstack((rng.uniform(0, 2 * np.pi, Np), rng.uniform(-3, 3, Np)))
+    yv = rng.standard_normal(2 * Np)
+    hyps = np.array([[0.4, 0.6, 1.0, 1e-2], [0.5, 0.7, 1.2, 2e-2]])
+    func.set_family("A")
+    got = func.nll_chol_batch(hyps, x, yv, 2 * Np)
+    for b, h in enumerate(hyps):
+        _, nll_o, _ = oracle.fit("A", x[:Np], x[Np:], yv, h[:-1], h[-1])
+        assert got[b] == pytest.approx(nll_o, rel=1e-10)
+    # NaN in one problem's targets
+    B, n_pts = 3, 12
+    X, Y = rng.uniform(0, 2 * np.pi, (B, n_pts)), rng.uniform(-3, 3, (B, n_pts))
+    Z = rng.standard_normal((B, 2 * n_pts))
+    Z[1, 5] = np.nan
+    al, nll, info = fit_batch("A", X, Y, Z, np.tile([0.6, 0.8, 1.0], (B, 1)), 1e-2)
+    assert np.all(info == 0) and np.isnan(nll[1]) and np.isfinite(nll[0]) and np.isfinite(nll[2])
+    assert np.all(np.isfinite(al[0])) and np.all(np.isfinite(al[2]))
