@@ -184,10 +184,12 @@ extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
     hipEvent_t a, b;
     SGPR_HIP(hipEventCreate(&a));
     SGPR_HIP(hipEventCreate(&b));
-    int rc = gemm_nt_diag(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, nullptr, t_probe_dbg, nullptr);  // warm
+    const char *be = getenv("SGPR_PROBE_BETA");   // 0: no read of C in the epilogue
+    const double beta = be ? atof(be) : 1.0;
+    int rc = gemm_nt_diag(m, n, k, -1.0, A, lda, B, ldb, beta, Cm, ldc, lower, nullptr, t_probe_dbg, nullptr);  // warm
     if (rc) return rc;
     SGPR_HIP(hipEventRecord(a, nullptr));
-    rc = gemm_nt_diag(m, n, k, -1.0, A, lda, B, ldb, 1.0, Cm, ldc, lower, st, t_probe_dbg, nullptr);
+    rc = gemm_nt_diag(m, n, k, -1.0, A, lda, B, ldb, beta, Cm, ldc, lower, st, t_probe_dbg, nullptr);
     SGPR_HIP(hipEventRecord(b, nullptr));
     if (rc) return rc;
     SGPR_HIP(hipEventSynchronize(b));
