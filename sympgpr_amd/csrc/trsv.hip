@@ -25,9 +25,13 @@
 // The chain itself is one product per strip: the tile whose segment arrives last is not streamed but folded
 // into the leaf inverse beforehand (M = inv L(s,s-1), a 128^3 product on the matrix cores), so that the
 // arrival of x_{s-1} is followed by  x_s = y - M x_{s-1}  wave by wave (16 rows each), without a workgroup
-// barrier; y = inv (b_s - streamed sums) is ready one strip earlier.  n = 16384: 7.4 -> 4.8 us per strip.
+// barrier; y = inv (b_s - streamed sums) is ready one strip earlier.  n = 16384: 7.4 -> 2.4 us per strip (b, op(inv) and the progress counter are fetched ahead of the chain).
 // L itself and the leaf inverses are read-only here: plain 16-byte loads.
 #include "common.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace sgpr {
 
@@ -49,6 +53,7 @@ struct TrsvArgs {
     double *pub;           // n doubles, all-ones on entry: the solved segments as the strips publish them
     int *state;            // [0] ticket, [1] ready (strips finished, in ticket order), [2] timeout flag
     int trans;
+    unsigned long long *dbg;
 };
 
 __device__ __forceinline__ void store_sc1(double *p, double v)
@@ -75,6 +80,11 @@ __device__ __forceinline__ void load_tile(const double *tile, size_t ld, int lan
     for (int j = 0; j < TS_CPW; ++j) reg[j] = *reinterpret_cast<const double2_t *>(p + (size_t)j * ld);
 }
 
+#ifdef SGPR_TRSV_DBG
+constexpr bool TRSV_DBG = true;
+#else
+constexpr bool TRSV_DBG = false;   // per-strip time stamps (experiments: make HIPFLAGS+=-DSGPR_TRSV_DBG)
+#endif
 constexpr int SLD = LEAF + 4;               // leading dimension of the staged tile: fragment reads (16 columns x 4 rows) hit every bank twice
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -113,11 +123,11 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
         auto seg_ptr = [&](int q) { return a.pub + (size_t)(fwd ? q : T - 1 - q) * LEAF; };
         const double *inv_tile = a.inv + (size_t)s * LEAF * LEAF;
         // op(inv), a row per lane: element (row i0 + l15, column colx_of(e)) of inv (forward) / inv^T
-        auto load_invx = [&](double2_t (&reg)[TS_CPW]) {
+        auto load_invx = [&](double2_t (&reg)[TS_CPW], const double *ib) {
 #pragma unroll
             for (int e = 0; e < 2 * TS_CPW; ++e) {
                 const int c = colx_of(e, l4);
-                const double v = fwd ? inv_tile[(size_t)(i0 + l15) + (size_t)c * LEAF] : inv_tile[(size_t)c + (size_t)(i0 + l15) * LEAF];
+                const double v = fwd ? ib[(size_t)(i0 + l15) + (size_t)c * LEAF] : ib[(size_t)c + (size_t)(i0 + l15) * LEAF];
                 if (e & 1) reg[e >> 1].y = v; else reg[e >> 1].x = v;
             }
         };
@@ -167,15 +177,30 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stg[(4 * jb + r) * TS_T + tid] = m[jb][r];   // parked until the end
         }
-        if (ns == 0) load_invx(cur);
+        // this thread's element of b is fetched now, not on the chain
+        double *bs = a.b + (size_t)s * LEAF;
+        const double bpre = fwd ? (tid < LEAF ? bs[tid] : 0.0) : bs[wave * TS_CPW + (lane >> 2)];
+        if (ns == 0) load_invx(cur, inv_tile);
         else load_tile(tile_ptr(0), a.ldl, lane, wave, cur);
         for (int q = 0; q < ns; ++q) {
             // the next tile's loads go out before anything that may wait
-            if (q + 1 < ns) load_tile(tile_ptr(q + 1), a.ldl, lane, wave, nxt);
+            // (behind the last streamed tile: op(inv), a row per lane; the base pointer is made opaque so that its 32
+            // addresses are formed here and not carried through the loop)
+            if (q + 1 < ns) {
+                load_tile(tile_ptr(q + 1), a.ldl, lane, wave, nxt);
+            } else {
+                const double *ib = inv_tile;
+                asm volatile("" : "+s"(ib));
+                load_invx(nxt, ib);
+            }
             // segment q: fetched one step ahead, or (at the frontier) polled for: the 128 lanes that carry
             // the segment poll the counter themselves and load their element the moment it moves
             if (q >= known) {
                 if (tid < LEAF) {
+                    // how far the others are (later segments up to there need no polling): read BEFORE the poll, so
+                    // that this second round trip is not paid between a segment's arrival and its use
+                    int prog = 0;
+                    if (tid == 0) prog = __hip_atomic_load((gi32 *)(a.state + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     unsigned spins = 0;
                     unsigned long long bits;
                     gu64 *src = (gu64 *)(seg_ptr(q) + tid);
@@ -185,11 +210,11 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
                     }
                     vec[q & 1][tid] = __longlong_as_double((long long)bits);
                     if (bits == UNPUBLISHED) __hip_atomic_store((gi32 *)(a.state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (tid == 0)   // how far the others are: later segments up to there need no polling
-                        sh[2 + (q & 1)] = bits == UNPUBLISHED ? -1 : __hip_atomic_load((gi32 *)(a.state + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tid == 0) sh[2 + (q & 1)] = bits == UNPUBLISHED ? -1 : prog;
                 }
                 __syncthreads();
                 const int r = sh[2 + (q & 1)];
+                if (TRSV_DBG && a.dbg && tid == 0 && q == ns - 1) a.dbg[4 * tk + 3] = __builtin_amdgcn_s_memrealtime();
                 if (r < 0) return;
                 known = r > q + 1 ? r : q + 1;
             } else {
@@ -217,10 +242,9 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
             for (int j = 0; j < TS_CPW; ++j) cur[j] = nxt[j];
         }
         // ---- t = b_s - (streamed sums), still one strip behind the frontier
-        double *bs = a.b + (size_t)s * LEAF;
-        if (ns > 0) load_invx(cur);                           // L2-warm: the M product read it a moment ago
         if (ns == 0) {
-            if (tid < LEAF) tv[tid] = bs[tid];
+            if (fwd) { if (tid < LEAF) tv[tid] = bpre; }
+            else if ((lane & 3) == 0) tv[wave * TS_CPW + (lane >> 2)] = bpre;
         } else if (fwd) {
             red[wave][2 * lane] = acc_r0;
             red[wave][2 * lane + 1] = acc_r1;
@@ -229,25 +253,33 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
                 double r = 0.0;
 #pragma unroll
                 for (int w = 0; w < TS_W; ++w) r += red[w][tid];
-                tv[tid] = bs[tid] - r;
+                tv[tid] = bpre - r;
             }
         } else {
-            // column sums: reduce each of the 16 accumulators over the wave's 64 lanes
+            // column sums over the wave's 64 lanes as a butterfly that halves the values a lane carries at every
+            // step (8 + 4 + 2 + 1 + 1 + 1 exchanges instead of 16 x 6): lane l ends with column l >> 2
+            double v8[8], v4[4], v2[2], v1;
+            const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-            for (int j = 0; j < TS_CPW; ++j) {
-                double v = acc_c[j];
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-                if (lane == 0) tv[wave * TS_CPW + j] = bs[wave * TS_CPW + j] - v;
-            }
+            for (int j = 0; j < 8; ++j) v8[j] = (b5 ? acc_c[8 + j] : acc_c[j]) + __shfl_xor(b5 ? acc_c[j] : acc_c[8 + j], 32, 64);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = (b4 ? v8[4 + j] : v8[j]) + __shfl_xor(b4 ? v8[j] : v8[4 + j], 16, 64);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v2[j] = (b3 ? v4[2 + j] : v4[j]) + __shfl_xor(b3 ? v4[j] : v4[2 + j], 8, 64);
+            v1 = (b2 ? v2[1] : v2[0]) + __shfl_xor(b2 ? v2[0] : v2[1], 4, 64);
+            v1 += __shfl_xor(v1, 2, 64);
+            v1 += __shfl_xor(v1, 1, 64);
+            if ((lane & 3) == 0) tv[wave * TS_CPW + (lane >> 2)] = bpre - v1;
         }
         __syncthreads();
-        // y = op(inv) t for this wave's 16 rows (op(inv) sits in cur, a row per lane): 32 products per lane,
-        // then the four lanes of a row add up
+        // y = op(inv) t for this wave's 16 rows (a row per lane): 32 products per lane, then the four lanes of a
+        // row add up
         double y = 0.0;
 #pragma unroll
         for (int e = 0; e < 2 * TS_CPW; ++e) y = __builtin_fma((e & 1) ? cur[e >> 1].y : cur[e >> 1].x, tv[colx_of(e, l4)], y);
         y += __shfl_xor(y, 16, 64);
         y += __shfl_xor(y, 32, 64);
+        if (TRSV_DBG && a.dbg && tid == 0) a.dbg[4 * tk + 0] = __builtin_amdgcn_s_memrealtime();
         if (tk > 0) {
             // ---- the chain: the last segment arrives -> x = y - M seg -> published, wave by wave
             double mm[2 * TS_CPW];
@@ -267,6 +299,7 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
                 __hip_atomic_store((gi32 *)(a.state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sh[1] = 1;
             }
+            if (TRSV_DBG && a.dbg && tid == 0) a.dbg[4 * tk + 1] = __builtin_amdgcn_s_memrealtime();
             double *vw = vecw[wave];
             *reinterpret_cast<double2_t *>(vw + 2 * lane) =
                 double2_t{__longlong_as_double((long long)b0), __longlong_as_double((long long)b1)};
@@ -283,6 +316,7 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
             publish(a.pub + (size_t)s * LEAF + i0 + l15, y);
             bs[i0 + l15] = y;
         }
+        if (TRSV_DBG && a.dbg && tid == 0) a.dbg[4 * tk + 2] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                      // every wave's part is out; LDS is reused by the next strip
         if (tid == 0) __hip_atomic_store((gi32 *)(a.state + 1), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -307,11 +341,32 @@ int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b
 {
     if (n <= 0) return 0;
     if (!trsv_strips_ok(n, L, ldl)) { set_error("trsv_strips: shape not supported"); return SGPR_E_ARG; }
-    TrsvArgs a{n / LEAF, L, ldl, inv, b, pub, state, trans};
+    TrsvArgs a{n / LEAF, L, ldl, inv, b, pub, state, trans, nullptr};
+    const bool dbg = TRSV_DBG && getenv("SGPR_TRSV_DBG") != nullptr;
+    if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * 4 * a.T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * 4 * a.T); }
     const int grid = a.T < 256 ? a.T : 256;
     if (trans) hipLaunchKernelGGL(trsv_strips_kernel<false>, dim3(grid), dim3(TS_T), 0, st, a);
     else       hipLaunchKernelGGL(trsv_strips_kernel<true>, dim3(grid), dim3(TS_T), 0, st, a);
     SGPR_CHECK_LAUNCH();
+    if (dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(4 * (size_t)a.T);
+        (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> hop, vis, cmp, slack, vis2, prep;
+        for (int t = 3; t < a.T; ++t) {
+            if (h[4 * t + 3]) { vis2.push_back(((double)h[4 * t + 3] - (double)h[4 * (t - 2) + 2]) * 0.01); prep.push_back(((double)h[4 * t + 0] - (double)h[4 * t + 3]) * 0.01); }
+            hop.push_back(((double)h[4 * t + 2] - (double)h[4 * (t - 1) + 2]) * 0.01);
+            vis.push_back(((double)h[4 * t + 1] - (double)h[4 * (t - 1) + 2]) * 0.01);
+            cmp.push_back(((double)h[4 * t + 2] - (double)h[4 * t + 1]) * 0.01);
+            slack.push_back(((double)h[4 * (t - 1) + 2] - (double)h[4 * t + 0]) * 0.01);
+        }
+        auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
+        auto q10 = [](std::vector<double> &x) { return x.empty() ? 0.0 : x[x.size() / 10]; };
+        fprintf(stderr, "publish(s-2) -> seen in stream (after barrier) med %.2f | -> y ready med %.2f us (%zu polled)\n", med(vis2), med(prep), prep.size());
+        fprintf(stderr, "trsv trans=%d T=%d: hop med %.2f us | publish(s-1) -> seen(s) med %.2f | seen -> publish med %.2f | y ready before publish(s-1): med %.2f p10 %.2f us | total %.1f us\n",
+                trans, a.T, med(hop), med(vis), med(cmp), med(slack), q10(slack), ((double)h[4 * (a.T - 1) + 2] - (double)h[2]) * 0.01);
+        (void)hipFree(a.dbg);
+    }
     return 0;
 }
 
