@@ -83,7 +83,7 @@ __device__ __forceinline__ void load_tile(const double *tile, size_t ld, int lan
 #ifdef SGPR_TRSV_DBG
 constexpr bool TRSV_DBG = true;
 #else
-constexpr bool TRSV_DBG = false;   // per-strip time stamps (experiments: make HIPFLAGS+=-DSGPR_TRSV_DBG)
+constexpr bool TRSV_DBG = false;   // per-strip time stamps (experiments: make EXTRA=-DSGPR_TRSV_DBG)
 #endif
 constexpr int SLD = LEAF + 4;               // leading dimension of the staged tile: fragment reads (16 columns x 4 rows) hit every bank twice
 typedef double double4_t __attribute__((ext_vector_type(4)));
