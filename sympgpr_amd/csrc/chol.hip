@@ -184,7 +184,7 @@ __global__ __launch_bounds__(MV_T) void trsv_block_kernel(int n, const double *L
 // order of the workgroups (a ticket), so every flag a workgroup waits for is set by a workgroup that
 // started before it.  Every spin is bounded; a timeout is reported through *dinfo (PANEL_TIMEOUT).
 constexpr int PW_MAX = 16;                      // leaf columns per panel (nb <= 2048)
-constexpr int PFLAG_STRIDE = 2 + PW_MAX + PW_MAX * PW_MAX + 6;   // ints of flag state per panel (280)
+constexpr int PFLAG_STRIDE = 2 + 2 * PW_MAX + PW_MAX * PW_MAX + 6;   // ints of flag state per panel (296)
 constexpr int PANEL_TIMEOUT = POTRF_HANDOFF_TIMEOUT;   // *dinfo value: a hand-off was never published
 constexpr int PANEL_G_MAX = 256;                // workgroups (each holds a whole CU: 133 KiB of LDS)
 
@@ -195,7 +195,7 @@ struct PanelArgs {
     double *inv;      // leaf inverses of this panel's W leaves (LEAF x LEAF each)
     int *dinfo;
     int goff;         // global index of the panel's first row / column (LAPACK info)
-    int *flags;       // PFLAG_STRIDE ints, zero on entry: [0] ticket, [2 + c] I[c], [2 + PW_MAX + r * PW_MAX + c] F[r][c]
+    int *flags;       // PFLAG_STRIDE ints, zero on entry: [0] ticket, [2 + c] I[c], [2 + PW_MAX + c] E[c], [2 + 2 PW_MAX + r * PW_MAX + c] F[r][c]
 };
 
 typedef __attribute__((address_space(1))) int gint;
@@ -252,6 +252,81 @@ __device__ __forceinline__ void panel_product(double *smem, double alpha, const 
     tile::gemm_body_dma<LEAF, LEAF, 2>(ga, smem, 0, 0);
 }
 
+// X (128 x 128, in place) := X inv(L_cc)^T WITHOUT the leaf's full inverse: a right-looking blocked solve over the
+// eight 16-column blocks,  X_j = S_j inv(L_jj)^T;  S_j' -= X_j L(j',j)^T for j' > j,  that needs L_cc and the
+// inverses of its 16 x 16 diagonal blocks only -- what a leaf hands over ~20 us before its full inverse (E[c]).
+// The rows of X are independent, so every wave takes 32 of them and runs alone: the tile lives in its MFMA
+// accumulators (row = lane & 15, column = 4 r + lane >> 4), and that layout IS the operand layout of the next
+// product (k = 4 r + lane >> 4), so X_j goes from one v_mfma to the next without touching LDS; only L_cc is
+// staged (once, by all four waves).  288 MFMAs per wave ~ 8 us against ~18 us for the product with inv(L_cc).
+// Used by the diagonal strips, i.e. on the chain  leaf -> solve -> update -> leaf  of the factorisation.
+__device__ __forceinline__ void panel_trsm(double *s, const double *Lcc, const double *invd, double *X, size_t lda)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // the previous task is done with the LDS buffer
+#pragma unroll 8
+    for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
+        const int idx = it * LT + tid;
+        const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
+        const double2_t v = *reinterpret_cast<const double2_t *>(Lcc + (size_t)i + (size_t)c * lda);
+        *reinterpret_cast<double2_t *>(s + c * LLD + i) = v;
+    }
+    // ... with the inverted 16 x 16 diagonal blocks in place of L's own (which this solve never reads)
+    double dinv[LEAF * PW / LT];
+#pragma unroll
+    for (int it = 0; it < LEAF * PW / LT; ++it) {
+        const int idx = it * LT + tid;
+        const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
+        dinv[it] = invd[(size_t)i + (size_t)c * LEAF];
+    }
+    double4_t acc[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[rb][j][r] = X[(size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda];
+    __syncthreads();                                   // (the staging loop above wrote the same words)
+#pragma unroll
+    for (int it = 0; it < LEAF * PW / LT; ++it) {
+        const int idx = it * LT + tid;
+        const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
+        s[c * LLD + i] = dinv[it];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            double4_t x = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64(s[(16 * j + 4 * kk + l4) * LLD + 16 * j + l15], acc[rb][j][kk], x, 0, 0, 0);
+            acc[rb][j] = x;
+        }
+#pragma unroll
+        for (int jj = j + 1; jj < 8; ++jj) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const double lneg = -s[(16 * j + 4 * kk + l4) * LLD + 16 * jj + l15];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, acc[rb][j][kk], acc[rb][jj], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                X[(size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda] = acc[rb][j][r];
+}
+
 __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
 {
     __shared__ double s[LEAF_LDS];     // the leaf's 128 x 130 block; the products stage through its first 72 KiB
@@ -264,7 +339,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
     __syncthreads();
     const int W = a.W, R = a.R, G = a.G;
     if (g >= G) return;
-    const int F0 = 2 + PW_MAX;
+    const int E0 = 2 + PW_MAX, F0 = 2 + 2 * PW_MAX;
     auto tileptr = [&](int r, int c) { return a.P + (size_t)r * LEAF + (size_t)c * LEAF * a.lda; };
     // Strips of this workgroup: workgroups 0..W-1 own one diagonal strip each (rows g of the diagonal
     // block, columns 0..g-1 to process, then their own leaf); the others share the strips below.
@@ -277,8 +352,8 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
         for (int c = 0; c < ncol; ++c) {
             bool have_inv = false, have_rows = false;
             for (int r = r_first; r < R; r += r_step) {
-                if (!have_inv) {                       // inv(L_cc) published by strip c's workgroup
-                    idx[0] = 2 + c;
+                if (!have_inv) {                       // inv(L_cc) published by strip c's workgroup (a diagonal
+                    idx[0] = diag ? E0 + c : 2 + c;    // strip needs its 16 x 16 diagonal blocks only: E[c])
                     if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
                     have_inv = true;
                 }
@@ -298,6 +373,10 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
                         }
                     }
                     const bool solve = t == 0;
+                    if (solve && diag) {
+                        panel_trsm(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, X, a.lda);
+                        continue;
+                    }
                     const double *B = solve ? a.inv + (size_t)c * LEAF * LEAF : tileptr(c + t, c);
                     panel_product(s, solve ? 1.0 : -1.0, X, a.lda, B, solve ? (size_t)LEAF : a.lda, solve ? 0.0 : 1.0,
                                   solve ? X : tileptr(r, c + t), a.lda);
@@ -310,7 +389,8 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, tileptr(g, g), a.lda,
-                  a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr);
+                  a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr,
+                  a.flags + E0 + g);
         panel_publish(a.flags + 2 + g);
     }
 }

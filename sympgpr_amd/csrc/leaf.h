@@ -30,7 +30,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sInv /* PW * (PW + 1) */,
                                           double *sRl /* PW: 1 / L11(j,j) of the current panel */, int nb,
                                           double *A, size_t lda, double *inv, int *dinfo, int goff, int mode,
-                                          unsigned long long *stamps)
+                                          unsigned long long *stamps, int *early_flag = nullptr)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -216,6 +216,22 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
                 if (i >= c) s[(d0 + c) * LLD + d0 + i] = x[i];
         }
         __syncthreads();
+    }
+    if (early_flag) {
+        // L (in A) and the inverses of its eight 16 x 16 diagonal blocks -- which ARE the diagonal blocks of
+        // inv(L) -- are all a blocked triangular solve against L needs (chol.hip, panel_trsm): hand them over
+        // now, ~20 us before the full inverse (agent-scope release as in panel_publish)
+        for (int idx = tid; idx < LEAF * PW; idx += LT) {
+            const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;     // row i, the 16 columns of its diagonal block
+            inv[(size_t)i + (size_t)c * LEAF] = (i >= c) ? s[c * LLD + i] : 0.0;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store((__attribute__((address_space(1))) int *)early_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     mark(5);
     // (I1) recursive doubling: with the diagonal blocks of size b inverted, the blocks of size 2b follow
