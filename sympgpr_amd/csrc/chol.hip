@@ -195,10 +195,17 @@ struct PanelArgs {
     double *inv;      // leaf inverses of this panel's W leaves (LEAF x LEAF each)
     int *dinfo;
     int goff;         // global index of the panel's first row / column (LAPACK info)
+    unsigned long long *dbg;   // per-leaf-column time stamps (8 each) or null; written only in -DSGPR_PANEL_DBG builds
     int *flags;       // PFLAG_STRIDE ints, zero on entry: [0] ticket, [2 + c] I[c], [2 + PW_MAX + c] E[c], [2 + 2 PW_MAX + r * PW_MAX + c] F[r][c]
 };
 
 typedef __attribute__((address_space(1))) int gint;
+#ifdef SGPR_PANEL_DBG
+constexpr bool PANEL_DBG = true;
+#else
+constexpr bool PANEL_DBG = false;    // make EXTRA=-DSGPR_PANEL_DBG + SGPR_PANEL_DBG=1: the chain's time stamps per leaf column
+#endif
+static unsigned long long *g_panel_dbg = nullptr;
 
 __device__ __forceinline__ void panel_publish(int *flag)
 {
@@ -210,6 +217,14 @@ __device__ __forceinline__ void panel_publish(int *flag)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store((gint *)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// the same for a payload that went out with write-through (sc1) stores only: no L2 write-back to wait for
+__device__ __forceinline__ void panel_publish_wt(int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store((gint *)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Wait until every flag in flags[idx[0..cnt)] is set.  Returns false (workgroup-uniform) on timeout.
@@ -252,60 +267,81 @@ __device__ __forceinline__ void panel_product(double *smem, double alpha, const 
     tile::gemm_body_dma<LEAF, LEAF, 2>(ga, smem, 0, 0);
 }
 
+// ---- the chain of the factorisation inside the panel kernel: solve -> update -> leaf in registers and LDS --------
 // X (128 x 128, in place) := X inv(L_cc)^T WITHOUT the leaf's full inverse: a right-looking blocked solve over the
 // eight 16-column blocks,  X_j = S_j inv(L_jj)^T;  S_j' -= X_j L(j',j)^T for j' > j,  that needs L_cc and the
 // inverses of its 16 x 16 diagonal blocks only -- what a leaf hands over ~20 us before its full inverse (E[c]).
 // The rows of X are independent, so every wave takes 32 of them and runs alone: the tile lives in its MFMA
 // accumulators (row = lane & 15, column = 4 r + lane >> 4), and that layout IS the operand layout of the next
 // product (k = 4 r + lane >> 4), so X_j goes from one v_mfma to the next without touching LDS; only L_cc is
-// staged (once, by all four waves).  288 MFMAs per wave ~ 8 us against ~18 us for the product with inv(L_cc).
-// Used by the diagonal strips, i.e. on the chain  leaf -> solve -> update -> leaf  of the factorisation.
-__device__ __forceinline__ void panel_trsm(double *s, const double *Lcc, const double *invd, double *X, size_t lda)
+// staged (its 28 blocks below the diagonal, and the inverted diagonal blocks in place of L's own).  288 MFMAs per
+// wave.  The tile is fetched BEFORE the wait for E[c] (trsm_prefetch): it has been final since the previous column.
+typedef double4_t XTile[2][8];      // this wave's 32 rows: [row block][16-column block][r]
+
+__device__ __forceinline__ void trsm_prefetch(const double *X, size_t lda, XTile &x)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // the previous task is done with the LDS buffer
-#pragma unroll 8
-    for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
-        const int idx = it * LT + tid;
-        const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
-        const double2_t v = *reinterpret_cast<const double2_t *>(Lcc + (size_t)i + (size_t)c * lda);
-        *reinterpret_cast<double2_t *>(s + c * LLD + i) = v;
-    }
-    // ... with the inverted 16 x 16 diagonal blocks in place of L's own (which this solve never reads)
-    double dinv[LEAF * PW / LT];
-#pragma unroll
-    for (int it = 0; it < LEAF * PW / LT; ++it) {
-        const int idx = it * LT + tid;
-        const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
-        dinv[it] = invd[(size_t)i + (size_t)c * LEAF];
-    }
-    double4_t acc[2][8];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[rb][j][r] = X[(size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda];
-    __syncthreads();                                   // (the staging loop above wrote the same words)
+                x[rb][j][r] = X[(size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda];
+}
+
+__device__ __forceinline__ void trsm_solve(double *s, const double *Lcc, const double *invd, size_t lda, XTile &x,
+                                           unsigned long long *st = nullptr)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    __syncthreads();                                   // the previous task is done with the LDS buffer
+    // the 28 blocks below the diagonal ones: 14 16-byte loads per thread, ALL in flight at once (one round trip to
+    // wherever the leaf's write-through stores went; in batches of 8 the staging took 8.7 us, four round trips)
+    double2_t lv[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        const int e = q * LT + tid;                    // 16-byte piece e of 28 blocks x 16 columns x 8 row pairs
+        const int blk = e >> 7, col = (e >> 3) & 15, rp = e & 7;
+        int bi = 1;
+        while ((bi + 1) * bi / 2 <= blk) ++bi;         // blk = bi (bi - 1) / 2 + bj, 0 <= bj < bi <= 7
+        const int bj = blk - bi * (bi - 1) / 2;
+        lv[q] = *reinterpret_cast<const double2_t *>(Lcc + (size_t)(16 * bi + 2 * rp) + (size_t)(16 * bj + col) * lda);
+    }
+    double dv[LEAF * PW / LT];
 #pragma unroll
     for (int it = 0; it < LEAF * PW / LT; ++it) {
         const int idx = it * LT + tid;
         const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
-        s[c * LLD + i] = dinv[it];
+        dv[it] = invd[(size_t)i + (size_t)c * LEAF];
+    }
+#pragma unroll
+    for (int q = 0; q < 14; ++q) {
+        const int e = q * LT + tid;
+        const int blk = e >> 7, col = (e >> 3) & 15, rp = e & 7;
+        int bi = 1;
+        while ((bi + 1) * bi / 2 <= blk) ++bi;
+        const int bj = blk - bi * (bi - 1) / 2;
+        *reinterpret_cast<double2_t *>(s + (16 * bj + col) * LLD + 16 * bi + 2 * rp) = lv[q];
+    }
+#pragma unroll
+    for (int it = 0; it < LEAF * PW / LT; ++it) {      // inv(L_jj) where L_jj would be
+        const int idx = it * LT + tid;
+        const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
+        s[c * LLD + i] = dv[it];
     }
     __syncthreads();
+    if (PANEL_DBG && st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            double4_t x = {0.0, 0.0, 0.0, 0.0};
+            double4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64(s[(16 * j + 4 * kk + l4) * LLD + 16 * j + l15], acc[rb][j][kk], x, 0, 0, 0);
-            acc[rb][j] = x;
+                y = __builtin_amdgcn_mfma_f64_16x16x4f64(s[(16 * j + 4 * kk + l4) * LLD + 16 * j + l15], x[rb][j][kk], y, 0, 0, 0);
+            x[rb][j] = y;
         }
 #pragma unroll
         for (int jj = j + 1; jj < 8; ++jj) {
@@ -314,17 +350,110 @@ __device__ __forceinline__ void panel_trsm(double *s, const double *Lcc, const d
                 const double lneg = -s[(16 * j + 4 * kk + l4) * LLD + 16 * jj + l15];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
-                    acc[rb][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, acc[rb][j][kk], acc[rb][jj], 0, 0, 0);
+                    x[rb][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, x[rb][j][kk], x[rb][jj], 0, 0, 0);
             }
         }
     }
+    if (PANEL_DBG && st && tid == 0) st[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+// write-through (sc1) stores: the flag that hands X over needs no L2 write-back (panel_publish_wt)
+__device__ __forceinline__ void trsm_store(double *X, size_t lda, const XTile &x)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                X[(size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda] = acc[rb][j][r];
+                store_wt(X + (size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda, x[rb][j][r]);
+}
+
+// The 36 16 x 16 blocks of the lower triangle of a 128 x 128 tile, nine per wave: block t = (mb, nb), mb >= nb
+__device__ __forceinline__ void lower_block(int t, int &mb, int &nb)
+{
+    mb = 0;
+    while ((mb + 1) * (mb + 2) / 2 <= t) ++mb;
+    nb = t - mb * (mb + 1) / 2;
+}
+typedef double4_t CTile[9];
+
+// this wave's nine blocks of C (row = 16 mb + lane & 15, column = 16 nb + 4 r + lane >> 4)
+__device__ __forceinline__ void diag_prefetch(const double *C, size_t lda, CTile &c)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        int mb, nb;
+        lower_block(9 * wave + p, mb, nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[p][r] = C[(size_t)(16 * mb + l15) + (size_t)(16 * nb + 4 * r + l4) * lda];
+    }
+}
+
+// C (the strip's diagonal tile) -= X X^T, lower blocks only, and straight into the leaf's LDS block: X goes
+// from the solve's accumulators into LDS as a [k][row] image, every wave multiplies its nine blocks out of it,
+// and the result lands where leaf_body expects the tile (strict upper triangle zero) -- no trip through memory
+// between the solve, the update and the factorisation of the chain.
+__device__ __forceinline__ void diag_multiply(double *s, const XTile &x, CTile &c, int (&mb)[9], int (&nb)[9])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    __syncthreads();                                   // every wave is done with L_cc in s
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[(16 * j + 4 * r + l4) * LLD + 32 * wave + 16 * rb + l15] = x[rb][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 9; ++p) lower_block(9 * wave + p, mb[p], nb[p]);
+#pragma unroll 2
+    for (int k = 0; k < LEAF / 4; ++k) {               // k-chunk of 4: rows 4 k + l4 of the image
+        const double *row = s + (4 * k + l4) * LLD + l15;
+#pragma unroll
+        for (int p = 0; p < 9; ++p)
+            c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-row[16 * nb[p]], row[16 * mb[p]], c[p], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void diag_update_into_leaf(double *s, const XTile &x, CTile &c)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int mb[9], nb[9];
+    diag_multiply(s, x, c, mb, nb);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the X stores of trsm_store: drained long ago)
+    __syncthreads();                                   // every wave is done with the image
+    for (int idx = tid; idx < LEAF * LEAF; idx += LT) {   // blocks above the diagonal: zero
+        const int i = idx % LEAF, cc = idx / LEAF;
+        if (i / PW < cc / PW) s[cc * LLD + i] = 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * mb[p] + l15, n = 16 * nb[p] + 4 * r + l4;
+            s[n * LLD + m] = (m >= n) ? c[p][r] : 0.0;
+        }
+    __syncthreads();
+}
+
+// the same update with the tile staying in memory (an earlier column of the strip): lower blocks only
+__device__ __forceinline__ void diag_update_global(double *s, const XTile &x, CTile &c, double *C, size_t lda)
+{
+    const int lane = threadIdx.x & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int mb[9], nb[9];
+    diag_multiply(s, x, c, mb, nb);
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(size_t)(16 * mb[p] + l15) + (size_t)(16 * nb[p] + 4 * r + l4) * lda] = c[p][r];
 }
 
 __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
@@ -341,57 +470,106 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
     if (g >= G) return;
     const int E0 = 2 + PW_MAX, F0 = 2 + 2 * PW_MAX;
     auto tileptr = [&](int r, int c) { return a.P + (size_t)r * LEAF + (size_t)c * LEAF * a.lda; };
-    // Strips of this workgroup: workgroups 0..W-1 own one diagonal strip each (rows g of the diagonal
-    // block, columns 0..g-1 to process, then their own leaf); the others share the strips below.
-    const bool diag = g < W;
-    const int nw = G - W;
-    const int r_first = diag ? g : W + (g - W), r_step = diag ? R : (nw > 0 ? nw : R);
-    const int ncol = diag ? g : W;
     int idx[PW_MAX];
-    if (!(diag && g == 0)) {
-        for (int c = 0; c < ncol; ++c) {
-            bool have_inv = false, have_rows = false;
-            for (int r = r_first; r < R; r += r_step) {
-                if (!have_inv) {                       // inv(L_cc) published by strip c's workgroup (a diagonal
-                    idx[0] = diag ? E0 + c : 2 + c;    // strip needs its 16 x 16 diagonal blocks only: E[c])
-                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
-                    have_inv = true;
-                }
-                double *X = tileptr(r, c);
-                const int last = min(W - 1, r);        // columns c+1..last of this strip take the update
-                for (int t = 0; t <= last - c; ++t) {
-                    if (t == 1) {
-                        // X = L(r,c) is complete: a diagonal strip hands it to the strips below it
-                        if (diag) panel_publish(a.flags + F0 + r * PW_MAX + c);
-                        // ... and the update needs L(c',c) of the diagonal strips c' in (c, last], other than r
-                        if (!have_rows) {
-                            int cnt = 0;
-                            for (int cc = c + 1; cc <= last; ++cc)
-                                if (cc != r) idx[cnt++] = F0 + cc * PW_MAX + c;
-                            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1)) return;
-                            have_rows = true;
-                        }
-                    }
-                    const bool solve = t == 0;
-                    if (solve && diag) {
-                        panel_trsm(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, X, a.lda);
-                        continue;
-                    }
-                    const double *B = solve ? a.inv + (size_t)c * LEAF * LEAF : tileptr(c + t, c);
-                    panel_product(s, solve ? 1.0 : -1.0, X, a.lda, B, solve ? (size_t)LEAF : a.lda, solve ? 0.0 : 1.0,
-                                  solve ? X : tileptr(r, c + t), a.lda);
-                }
-            }
+    if (g < W) {
+        // ---- a diagonal strip: row g of the diagonal block, columns 0..g-1, then its own leaf.  Its solves need
+        // E[c] only; the last column (c = g - 1) is the chain: solve -> update of (g,g) -> leaf without leaving the CU
+        const bool dbg = PANEL_DBG && a.dbg && tid == 0;
+        for (int c = 0; c + 1 < g; ++c) {
+            double *X = tileptr(g, c);
+            XTile x;
+            CTile cd;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the updates this workgroup applied to (g,c) have
+            __syncthreads();                                      // landed, whichever wave stored them
+            trsm_prefetch(X, a.lda, x);
+            diag_prefetch(tileptr(g, g), a.lda, cd);
+            idx[0] = E0 + c;
+            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+            trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
+            trsm_store(X, a.lda, x);
+            // X = L(g,c) goes to the strips below; the strip's own diagonal tile takes X X^T straight from the
+            // accumulators (lower blocks only); the update of its tiles (g, c+1..g-1) needs L(c',c) of the diagonal
+            // strips c' in (c, g)
+            panel_publish_wt(a.flags + F0 + g * PW_MAX + c);
+            diag_update_global(s, x, cd, tileptr(g, g), a.lda);
+            int cnt = 0;
+            for (int cc = c + 1; cc < g; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
+            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1)) return;
+            for (int t = 1; t < g - c; ++t)
+                panel_product(s, -1.0, X, a.lda, tileptr(c + t, c), a.lda, 1.0, tileptr(g, c + t), a.lda);
         }
-    }
-    if (diag) {
+        if (g > 0) {
+            const int c = g - 1;
+            double *X = tileptr(g, c);
+            XTile x;
+            CTile cd;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's updates of (g,c) and (g,g) have landed
+            __syncthreads();
+            trsm_prefetch(X, a.lda, x);
+            diag_prefetch(tileptr(g, g), a.lda, cd);
+            idx[0] = E0 + c;
+            if (dbg) a.dbg[8 * g + 2] = __builtin_amdgcn_s_memrealtime();
+            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+            if (dbg) a.dbg[8 * g + 0] = __builtin_amdgcn_s_memrealtime();
+            trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x, a.dbg ? a.dbg + 8 * g + 6 : nullptr);
+            trsm_store(X, a.lda, x);
+            if (dbg) a.dbg[8 * g + 1] = __builtin_amdgcn_s_memrealtime();
+            diag_update_into_leaf(s, x, cd);           // (ends behind a barrier that every wave's drained X stores precede)
+            if (tid == 0) __hip_atomic_store((gint *)(a.flags + F0 + g * PW_MAX + c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (dbg) a.dbg[8 * g + 3] = __builtin_amdgcn_s_memrealtime();
+        }
         // this strip's diagonal tile has taken the updates of all earlier columns: factor + invert it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (dbg) a.dbg[8 * g + 4] = __builtin_amdgcn_s_memrealtime();
         leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, tileptr(g, g), a.lda,
                   a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr,
-                  a.flags + E0 + g);
+                  a.flags + E0 + g, g > 0);
         panel_publish(a.flags + 2 + g);
+        if (dbg) a.dbg[8 * g + 5] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
+    // ---- strips below the diagonal block, shared round-robin by the other workgroups: products with inv(L_cc)
+    const int nw = G - W;
+    const int r_first = W + (g - W), r_step = nw > 0 ? nw : R;
+    for (int c = 0; c < W; ++c) {
+        bool have_inv = false, have_rows = false;
+        for (int r = r_first; r < R; r += r_step) {
+            double *X = tileptr(r, c);
+            if (c == W - 1) {
+                // the last column: nothing follows the solve, and the kernel ends with it -- take the blocked solve,
+                // which can start on E[c], ~20 us before the leaf's full inverse is there
+                XTile x;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                trsm_prefetch(X, a.lda, x);
+                if (!have_inv) {
+                    idx[0] = E0 + c;
+                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+                    have_inv = true;
+                }
+                trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
+                trsm_store(X, a.lda, x);
+                continue;
+            }
+            if (!have_inv) {                           // inv(L_cc) published by strip c's workgroup
+                idx[0] = 2 + c;
+                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+                have_inv = true;
+            }
+            for (int t = 0; t <= W - 1 - c; ++t) {     // columns c+1..W-1 of this strip take the update
+                if (t == 1 && !have_rows) {            // ... which needs L(c',c) of the diagonal strips c' in (c, W)
+                    int cnt = 0;
+                    for (int cc = c + 1; cc < W; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
+                    if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1)) return;
+                    have_rows = true;
+                }
+                const bool solve = t == 0;
+                const double *B = solve ? a.inv + (size_t)c * LEAF * LEAF : tileptr(c + t, c);
+                panel_product(s, solve ? 1.0 : -1.0, X, a.lda, B, solve ? (size_t)LEAF : a.lda, solve ? 0.0 : 1.0,
+                              solve ? X : tileptr(r, c + t), a.lda);
+            }
+        }
     }
 }
 
@@ -690,6 +868,7 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
             pa.inv = cp.inv + (size_t)t0 * LEAF * LEAF;
             pa.dinfo = cp.dinfo; pa.goff = off0 + k0;
             pa.flags = c.flags + (size_t)t0 * PFLAG_STRIDE;
+            pa.dbg = g_panel_dbg ? g_panel_dbg + (size_t)8 * t0 : nullptr;
             hipLaunchKernelGGL(panel_kernel, dim3(pa.G), dim3(LT), 0, sp, pa);
             SGPR_CHECK_LAUNCH();
             if (split) return trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
@@ -779,9 +958,42 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     // (SGPR_LA_MAX overrides; measured crossover of round 1)
     static const int la_max_env = [] { const char *e = getenv("SGPR_LA_MAX"); return e ? atoi(e) : 57344; }();
     Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : la_max_env, flags};
+    const bool dbg = PANEL_DBG && getenv("SGPR_PANEL_DBG") != nullptr;
+    const int T = (n + LEAF - 1) / LEAF;
+    if (dbg) {
+        (void)hipMalloc((void **)&g_panel_dbg, sizeof(unsigned long long) * 8 * T);
+        (void)hipMemset(g_panel_dbg, 0, sizeof(unsigned long long) * 8 * T);
+    }
+    int rc;
     if (mode == 2 || (nb_env > 0 && mode == 0 && n > 4 * LEAF && n <= c.la_max))
-        return potrf_lookahead(n, A, lda, c, nb_env > 0 ? nb_env : 0, 0);
-    return potrf_rec(n, A, lda, 0, c);
+        rc = potrf_lookahead(n, A, lda, c, nb_env > 0 ? nb_env : 0, 0);
+    else
+        rc = potrf_rec(n, A, lda, 0, c);
+    if (dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(8 * (size_t)T);
+        (void)hipMemcpy(h.data(), g_panel_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(g_panel_dbg);
+        g_panel_dbg = nullptr;
+        std::vector<double> d[6];
+        for (int t = 1; t + 1 < T; ++t) {
+            const unsigned long long *p = &h[8 * t], *q = &h[8 * (t + 1)];
+            if (!p[0] || !p[5] || !q[0]) continue;               // first column of a panel: no chain stamps
+            d[0].push_back((p[1] - p[0]) * 0.01);                 // E seen -> solve done
+            d[1].push_back((p[2] - p[1]) * 0.01);                 // -> F published (at t == 1 entry)
+            d[2].push_back((p[3] - p[2]) * 0.01);                 // -> update done
+            d[3].push_back((p[4] - p[3]) * 0.01);                 // -> leaf entered
+            d[4].push_back(((double)q[0] - (double)p[4]) * 0.01); // leaf entered -> next strip saw E
+            d[5].push_back((p[5] - p[4]) * 0.01);                 // whole leaf incl. inverse + publish
+            d[3].back() = ((double)q[0] - (double)q[2]) * 0.01;   // how long the next strip waited for E
+            d[1].back() = (p[6] - p[0]) * 0.01;                   // E seen -> L staged
+            d[2].back() = (p[7] - p[6]) * 0.01;                   // -> MFMA part done
+        }
+        auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
+        fprintf(stderr, "panel chain n=%d (%zu columns): E seen -> solve stored %.1f | E seen -> staged %.1f | -> MFMA part done %.1f | (next strip waited for E %.1f) | "
+                "leaf entry -> next E seen %.1f | whole leaf %.1f us\n", n, d[0].size(), med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]), med(d[5]));
+    }
+    return rc;
 }
 
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,

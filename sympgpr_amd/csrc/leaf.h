@@ -16,6 +16,13 @@ enum { LEAF_FACTOR = 0, LEAF_INVERT_ONLY = 1 };
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// agent-scope write-through (sc1) 8-byte store
+__device__ __forceinline__ void store_wt(double *p, double v)
+{
+    __hip_atomic_store((__attribute__((address_space(1))) unsigned long long *)p, (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // A (nb x nb, lower, global) -> L in place (mode FACTOR) and inv(L) -> inv (LEAF x LEAF,
 // ld LEAF, zero-filled outside the nb x nb lower triangle).
 //
@@ -30,7 +37,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sInv /* PW * (PW + 1) */,
                                           double *sRl /* PW: 1 / L11(j,j) of the current panel */, int nb,
                                           double *A, size_t lda, double *inv, int *dinfo, int goff, int mode,
-                                          unsigned long long *stamps, int *early_flag = nullptr)
+                                          unsigned long long *stamps, int *early_flag = nullptr, bool preloaded = false)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -45,7 +52,9 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
         }
     };
 
-    if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
+    if (preloaded) {
+        // the caller has put the tile into s (strict upper triangle zero) behind a barrier: chol.hip, the chain
+    } else if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
         // full leaf: 32 independent 16-B loads per thread (the whole square is read, the strict
         // upper triangle -- whatever it holds -- is replaced by zeros on the way into LDS)
 #pragma unroll 8
@@ -181,8 +190,15 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
                 const int idx = it * LT + tid;
                 const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
                 double *dst = A + (size_t)i + (size_t)c * lda;
-                if (i >= c) *reinterpret_cast<double2_t *>(dst) = double2_t{s[c * LLD + i], s[c * LLD + i + 1]};
-                else if (i + 1 >= c) dst[1] = s[c * LLD + i + 1];
+                if (early_flag) {
+                    // handed over early: write-through (sc1) stores, so that the flag needs no L2 write-back
+                    if (i >= c) store_wt(dst, s[c * LLD + i]);
+                    if (i + 1 >= c) store_wt(dst + 1, s[c * LLD + i + 1]);
+                } else if (i >= c) {
+                    *reinterpret_cast<double2_t *>(dst) = double2_t{s[c * LLD + i], s[c * LLD + i + 1]};
+                } else if (i + 1 >= c) {
+                    dst[1] = s[c * LLD + i + 1];
+                }
             }
         } else {
             for (int idx = tid; idx < nb * nb; idx += LT) {
@@ -223,15 +239,14 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
         // now, ~20 us before the full inverse (agent-scope release as in panel_publish)
         for (int idx = tid; idx < LEAF * PW; idx += LT) {
             const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;     // row i, the 16 columns of its diagonal block
-            inv[(size_t)i + (size_t)c * LEAF] = (i >= c) ? s[c * LLD + i] : 0.0;
+            store_wt(inv + (size_t)i + (size_t)c * LEAF, (i >= c) ? s[c * LLD + i] : 0.0);
         }
+        // every byte handed over here (L above, these blocks) went out write-through: drained stores, the
+        // workgroup's barrier, then the flag -- no release fence (MI355X_MICROARCH.md, publish-large: 3 vs 8 us)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0)
             __hip_atomic_store((__attribute__((address_space(1))) int *)early_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
     mark(5);
     // (I1) recursive doubling: with the diagonal blocks of size b inverted, the blocks of size 2b follow
