@@ -276,7 +276,20 @@ __device__ __forceinline__ void panel_product(double *smem, double alpha, const 
 // product (k = 4 r + lane >> 4), so X_j goes from one v_mfma to the next without touching LDS; only L_cc is
 // staged (its 28 blocks below the diagonal, and the inverted diagonal blocks in place of L's own).  288 MFMAs per
 // wave.  The tile is fetched BEFORE the wait for E[c] (trsm_prefetch): it has been final since the previous column.
+// leading dimension of the LDS images the matrix cores read their operands from here: 16 rows x 4 k-columns per
+// fragment read, so the column stride must put k, k+1 32 banks apart (144 * 8 B = 2 * 576 B): conflict-free.  With the
+// leaf's own 130 the same reads were 2-4-way conflicts and the X X^T update took 17 us instead of 9.
+constexpr int ILD = LEAF + 16;
 typedef double4_t XTile[2][8];      // this wave's 32 rows: [row block][16-column block][r]
+
+// block t = 0..27 of the strictly lower 16 x 16 blocks of a 128 x 128 tile: t = bi (bi - 1) / 2 + bj, 0 <= bj < bi <= 7
+__device__ __forceinline__ constexpr int below_bi(int t)
+{
+    int bi = 1;
+    while ((bi + 1) * bi / 2 <= t) ++bi;
+    return bi;
+}
+__device__ __forceinline__ constexpr int below_bj(int t) { return t - below_bi(t) * (below_bi(t) - 1) / 2; }
 
 __device__ __forceinline__ void trsm_prefetch(const double *X, size_t lda, XTile &x)
 {
@@ -302,11 +315,11 @@ __device__ __forceinline__ void trsm_solve(double *s, const double *Lcc, const d
     double2_t lv[14];
 #pragma unroll
     for (int q = 0; q < 14; ++q) {
-        const int e = q * LT + tid;                    // 16-byte piece e of 28 blocks x 16 columns x 8 row pairs
-        const int blk = e >> 7, col = (e >> 3) & 15, rp = e & 7;
-        int bi = 1;
-        while ((bi + 1) * bi / 2 <= blk) ++bi;         // blk = bi (bi - 1) / 2 + bj, 0 <= bj < bi <= 7
-        const int bj = blk - bi * (bi - 1) / 2;
+        // 16-byte piece e = 256 q + tid of 28 blocks x 16 columns x 8 row pairs: block 2 q + (tid >> 7), a compile-
+        // time pair per q (a per-lane search for it cost 3 us: the loop diverges)
+        const int col = (tid >> 3) & 15, rp = tid & 7;
+        const int bi = (tid & 128) ? below_bi(2 * q + 1) : below_bi(2 * q);
+        const int bj = (tid & 128) ? below_bj(2 * q + 1) : below_bj(2 * q);
         lv[q] = *reinterpret_cast<const double2_t *>(Lcc + (size_t)(16 * bi + 2 * rp) + (size_t)(16 * bj + col) * lda);
     }
     double dv[LEAF * PW / LT];
@@ -316,20 +329,22 @@ __device__ __forceinline__ void trsm_solve(double *s, const double *Lcc, const d
         const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
         dv[it] = invd[(size_t)i + (size_t)c * LEAF];
     }
+    if (PANEL_DBG && st) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) st[-3] = __builtin_amdgcn_s_memrealtime();   // slot 3
+    }
 #pragma unroll
     for (int q = 0; q < 14; ++q) {
-        const int e = q * LT + tid;
-        const int blk = e >> 7, col = (e >> 3) & 15, rp = e & 7;
-        int bi = 1;
-        while ((bi + 1) * bi / 2 <= blk) ++bi;
-        const int bj = blk - bi * (bi - 1) / 2;
-        *reinterpret_cast<double2_t *>(s + (16 * bj + col) * LLD + 16 * bi + 2 * rp) = lv[q];
+        const int col = (tid >> 3) & 15, rp = tid & 7;
+        const int bi = (tid & 128) ? below_bi(2 * q + 1) : below_bi(2 * q);
+        const int bj = (tid & 128) ? below_bj(2 * q + 1) : below_bj(2 * q);
+        *reinterpret_cast<double2_t *>(s + (16 * bj + col) * ILD + 16 * bi + 2 * rp) = -lv[q];   // -L: S_j' += X_j (-L)^T
     }
 #pragma unroll
     for (int it = 0; it < LEAF * PW / LT; ++it) {      // inv(L_jj) where L_jj would be
         const int idx = it * LT + tid;
         const int i = idx % LEAF, c = (i / PW) * PW + idx / LEAF;
-        s[c * LLD + i] = dv[it];
+        s[c * ILD + i] = dv[it];
     }
     __syncthreads();
     if (PANEL_DBG && st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
@@ -340,14 +355,14 @@ __device__ __forceinline__ void trsm_solve(double *s, const double *Lcc, const d
             double4_t y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                y = __builtin_amdgcn_mfma_f64_16x16x4f64(s[(16 * j + 4 * kk + l4) * LLD + 16 * j + l15], x[rb][j][kk], y, 0, 0, 0);
+                y = __builtin_amdgcn_mfma_f64_16x16x4f64(s[(16 * j + 4 * kk + l4) * ILD + 16 * j + l15], x[rb][j][kk], y, 0, 0, 0);
             x[rb][j] = y;
         }
 #pragma unroll
         for (int jj = j + 1; jj < 8; ++jj) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const double lneg = -s[(16 * j + 4 * kk + l4) * LLD + 16 * jj + l15];
+                const double lneg = s[(16 * j + 4 * kk + l4) * ILD + 16 * jj + l15];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
                     x[rb][jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(lneg, x[rb][j][kk], x[rb][jj], 0, 0, 0);
@@ -371,34 +386,58 @@ __device__ __forceinline__ void trsm_store(double *X, size_t lda, const XTile &x
                 store_wt(X + (size_t)(32 * wave + 16 * rb + l15) + (size_t)(16 * j + 4 * r + l4) * lda, x[rb][j][r]);
 }
 
-// The 36 16 x 16 blocks of the lower triangle of a 128 x 128 tile, nine per wave: block t = (mb, nb), mb >= nb
-__device__ __forceinline__ void lower_block(int t, int &mb, int &nb)
-{
-    mb = 0;
-    while ((mb + 1) * (mb + 2) / 2 <= t) ++mb;
-    nb = t - mb * (mb + 1) / 2;
-}
+// The 36 16 x 16 blocks of the lower triangle of a 128 x 128 tile, nine per wave, as block PAIRS {b, b'} of the
+// eight row blocks: two {b,b}, two each with b' - b = 1, 2, 3 (mod 8) and one with b' - b = 4.  In terms of eight
+// SLOTS the nine pairs are the same for every wave -- only the slot -> block map depends on the wave -- so the
+// registers the MFMAs name are compile-time while the LDS / memory addresses carry the wave:
+//   slot i = 0..4 -> block (2 w + i) mod 8,   slot 6 -> block w,   slot 7 -> block w + 4
+// A pair whose first block is the smaller one is the TRANSPOSE of a lower block (C is symmetric): it is fetched
+// and stored with rows and columns exchanged.
+constexpr int DP[9][2] = {{0, 0}, {1, 1}, {1, 0}, {2, 0}, {3, 0}, {2, 1}, {3, 1}, {4, 1}, {7, 6}};   // (rows' slot, columns' slot)
 typedef double4_t CTile[9];
+struct DiagMap {
+    int blk[8];
+    __device__ __forceinline__ DiagMap(int wave)
+    {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) blk[i] = (2 * wave + i) & 7;
+        blk[5] = 0; blk[6] = wave; blk[7] = wave + 4;
+    }
+    // Pair p in a column-major tile with leading dimension ld: element r of lane (l15, l4) sits at
+    // base + voff + r * rstep, where base and rstep are wave-uniform and voff is one of two per-lane offsets.
+    // (accumulator: rows <- l15 of block bp, columns <- 4 r + l4 of block bq; bp < bq: the transposed block)
+    __device__ __forceinline__ void where(int p, size_t ld, int l15, int l4, size_t &base, unsigned &voff, size_t &rstep, bool &diagonal) const
+    {
+        const int bp = blk[DP[p][0]], bq = blk[DP[p][1]];
+        const bool lower = bp >= bq;
+        base = lower ? (size_t)16 * bp + (size_t)16 * bq * ld : (size_t)16 * bq + (size_t)16 * bp * ld;
+        voff = lower ? (unsigned)l15 + (unsigned)l4 * (unsigned)ld : (unsigned)l4 + (unsigned)l15 * (unsigned)ld;   // < 2^31: ld <= 2^24
+        rstep = lower ? 4 * ld : 4;
+        diagonal = bp == bq;
+    }
+};
 
-// this wave's nine blocks of C (row = 16 mb + lane & 15, column = 16 nb + 4 r + lane >> 4)
+// this wave's nine blocks of C
 __device__ __forceinline__ void diag_prefetch(const double *C, size_t lda, CTile &c)
 {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
+    const DiagMap dm(wave);
 #pragma unroll
     for (int p = 0; p < 9; ++p) {
-        int mb, nb;
-        lower_block(9 * wave + p, mb, nb);
+        size_t base, rstep;
+        unsigned voff;
+        bool dg;
+        dm.where(p, lda, l15, l4, base, voff, rstep, dg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[p][r] = C[(size_t)(16 * mb + l15) + (size_t)(16 * nb + 4 * r + l4) * lda];
+        for (int r = 0; r < 4; ++r) c[p][r] = (C + base + r * rstep)[voff];   // uniform pointer + 32-bit lane offset
     }
 }
 
-// C (the strip's diagonal tile) -= X X^T, lower blocks only, and straight into the leaf's LDS block: X goes
-// from the solve's accumulators into LDS as a [k][row] image, every wave multiplies its nine blocks out of it,
-// and the result lands where leaf_body expects the tile (strict upper triangle zero) -- no trip through memory
-// between the solve, the update and the factorisation of the chain.
-__device__ __forceinline__ void diag_multiply(double *s, const XTile &x, CTile &c, int (&mb)[9], int (&nb)[9])
+// C (the strip's diagonal tile) -= X X^T, lower blocks only: X goes from the solve's accumulators into LDS as a
+// [k][row] image, every wave multiplies its nine blocks out of it (per k-chunk: the fragments of its seven row
+// blocks, fetched one chunk ahead, then nine MFMAs on registers).
+__device__ __forceinline__ void diag_multiply(double *s, const XTile &x, CTile &c, unsigned long long *st = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -408,65 +447,94 @@ __device__ __forceinline__ void diag_multiply(double *s, const XTile &x, CTile &
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[(16 * j + 4 * r + l4) * LLD + 32 * wave + 16 * rb + l15] = x[rb][j][r];
+            for (int r = 0; r < 4; ++r) s[(16 * j + 4 * r + l4) * ILD + 32 * wave + 16 * rb + l15] = x[rb][j][r];
     __syncthreads();
+    if (PANEL_DBG && st && tid == 0) st[0] = __builtin_amdgcn_s_memrealtime();
+    const DiagMap dm(wave);
+    double f[2][8];
+    auto fetch = [&](int k, double (&ff)[8]) {
+        const double *row = s + (4 * k + l4) * ILD + l15;
 #pragma unroll
-    for (int p = 0; p < 9; ++p) lower_block(9 * wave + p, mb[p], nb[p]);
-#pragma unroll 2
-    for (int k = 0; k < LEAF / 4; ++k) {               // k-chunk of 4: rows 4 k + l4 of the image
-        const double *row = s + (4 * k + l4) * LLD + l15;
+        for (int i = 0; i < 8; ++i)
+            if (i != 5) ff[i] = row[16 * dm.blk[i]];
+    };
+    fetch(0, f[0]);
+#pragma unroll 4
+    for (int k = 0; k < LEAF / 4; ++k) {
+        if (k + 1 < LEAF / 4) fetch(k + 1, f[(k + 1) & 1]);
 #pragma unroll
         for (int p = 0; p < 9; ++p)
-            c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-row[16 * nb[p]], row[16 * mb[p]], c[p], 0, 0, 0);
+            c[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-f[k & 1][DP[p][1]], f[k & 1][DP[p][0]], c[p], 0, 0, 0);
     }
+    if (PANEL_DBG && st && tid == 0) st[2] = __builtin_amdgcn_s_memrealtime();
 }
 
-__device__ __forceinline__ void diag_update_into_leaf(double *s, const XTile &x, CTile &c)
+// ... and straight into the leaf's LDS block, where leaf_body expects the tile: no trip through memory between
+// the solve, the update and the factorisation of the chain
+__device__ __forceinline__ void diag_update_into_leaf(double *s, const XTile &x, CTile &c, unsigned long long *st = nullptr)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    int mb[9], nb[9];
-    diag_multiply(s, x, c, mb, nb);
+    diag_multiply(s, x, c, st);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the X stores of trsm_store: drained long ago)
     __syncthreads();                                   // every wave is done with the image
-    for (int idx = tid; idx < LEAF * LEAF; idx += LT) {   // blocks above the diagonal: zero
-        const int i = idx % LEAF, cc = idx / LEAF;
-        if (i / PW < cc / PW) s[cc * LLD + i] = 0.0;
+    // (the blocks above the diagonal keep whatever the image left there: leaf_body never reads them -- every
+    // read of s in it is on or below the diagonal, or masked by a select)
+    const DiagMap dm(wave);
+#pragma unroll
+    for (int p = 0; p < 9; ++p) {
+        size_t base, rstep;
+        unsigned voff;
+        bool dg;
+        dm.where(p, LLD, l15, l4, base, voff, rstep, dg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[base + voff + r * rstep] = (!dg || l15 >= 4 * r + l4) ? c[p][r] : 0.0;
     }
-#pragma unroll
-    for (int p = 0; p < 9; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = 16 * mb[p] + l15, n = 16 * nb[p] + 4 * r + l4;
-            s[n * LLD + m] = (m >= n) ? c[p][r] : 0.0;
-        }
     __syncthreads();
 }
 
-// the same update with the tile staying in memory (an earlier column of the strip): lower blocks only
+// the same update with the tile staying in memory (an earlier column of the strip)
 __device__ __forceinline__ void diag_update_global(double *s, const XTile &x, CTile &c, double *C, size_t lda)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    int mb[9], nb[9];
-    diag_multiply(s, x, c, mb, nb);
+    diag_multiply(s, x, c);
+    const DiagMap dm(wave);
 #pragma unroll
-    for (int p = 0; p < 9; ++p)
+    for (int p = 0; p < 9; ++p) {
+        size_t base, rstep;
+        unsigned voff;
+        bool dg;
+        dm.where(p, lda, l15, l4, base, voff, rstep, dg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(size_t)(16 * mb[p] + l15) + (size_t)(16 * nb[p] + 4 * r + l4) * lda] = c[p][r];
+        for (int r = 0; r < 4; ++r) (C + base + r * rstep)[voff] = c[p][r];
+    }
 }
 
 __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
 {
-    __shared__ double s[LEAF_LDS];     // the leaf's 128 x 130 block; the products stage through its first 72 KiB
+    __shared__ double s[LEAF * ILD];   // the leaf's 128 x 130 block / the chain's 128 x 144 images; the products stage through its first 72 KiB
     __shared__ int sh[2];
-    static_assert(2 * tile::BK * 2 * (LEAF + tile::PAD) <= LEAF_LDS, "product staging fits the leaf buffer");
+    static_assert(2 * tile::BK * 2 * (LEAF + tile::PAD) <= LEAF_LDS && LEAF_LDS <= LEAF * ILD, "product staging and the leaf fit the buffer");
     const int tid = threadIdx.x;
-    if (tid == 0) sh[0] = atomicAdd(a.flags, 1);
+    const int W = a.W, R = a.R, G = a.G;
+    // Two tickets.  The diagonal strips -- the chain -- go to workgroups whose id is a multiple of 8, i.e. (with the
+    // dispatcher's round-robin) to ONE XCD, so that what a leaf hands to the next strip is found in that XCD's L2
+    // and not in memory; the strips below go to everybody else, and to the leftovers of the first kind.  Arrival
+    // order within each kind: a workgroup still only waits for flags of workgroups that started before it or of
+    // diagonal strips, which the first eligible workgroups to arrive take (the placement is a speed-only assumption).
+    if (tid == 0) {
+        int t = -1;
+        if ((blockIdx.x & 7) == 0) {
+            t = atomicAdd(a.flags, 1);
+            if (t >= W) t = -1;
+        }
+        if (t < 0) t = W + atomicAdd(a.flags + 1, 1);
+        sh[0] = t;
+    }
     __syncthreads();
     const int g = sh[0];
     __syncthreads();
-    const int W = a.W, R = a.R, G = a.G;
     if (g >= G) return;
     const int E0 = 2 + PW_MAX, F0 = 2 + 2 * PW_MAX;
     auto tileptr = [&](int r, int c) { return a.P + (size_t)r * LEAF + (size_t)c * LEAF * a.lda; };
@@ -508,25 +576,24 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             trsm_prefetch(X, a.lda, x);
             diag_prefetch(tileptr(g, g), a.lda, cd);
             idx[0] = E0 + c;
-            if (dbg) a.dbg[8 * g + 2] = __builtin_amdgcn_s_memrealtime();
+            if (dbg) a.dbg[16 * g + 2] = __builtin_amdgcn_s_memrealtime();
             if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
-            if (dbg) a.dbg[8 * g + 0] = __builtin_amdgcn_s_memrealtime();
-            trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x, a.dbg ? a.dbg + 8 * g + 6 : nullptr);
+            if (dbg) a.dbg[16 * g + 0] = __builtin_amdgcn_s_memrealtime();
+            trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x, a.dbg ? a.dbg + 16 * g + 6 : nullptr);
             trsm_store(X, a.lda, x);
-            if (dbg) a.dbg[8 * g + 1] = __builtin_amdgcn_s_memrealtime();
-            diag_update_into_leaf(s, x, cd);           // (ends behind a barrier that every wave's drained X stores precede)
+            if (dbg) a.dbg[16 * g + 1] = __builtin_amdgcn_s_memrealtime();
+            diag_update_into_leaf(s, x, cd, a.dbg ? a.dbg + 16 * g + 8 : nullptr);           // (ends behind a barrier that every wave's drained X stores precede)
             if (tid == 0) __hip_atomic_store((gint *)(a.flags + F0 + g * PW_MAX + c), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (dbg) a.dbg[8 * g + 3] = __builtin_amdgcn_s_memrealtime();
         }
         // this strip's diagonal tile has taken the updates of all earlier columns: factor + invert it
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (dbg) a.dbg[8 * g + 4] = __builtin_amdgcn_s_memrealtime();
+        if (dbg) a.dbg[16 * g + 4] = __builtin_amdgcn_s_memrealtime();
         leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, tileptr(g, g), a.lda,
                   a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr,
                   a.flags + E0 + g, g > 0);
         panel_publish(a.flags + 2 + g);
-        if (dbg) a.dbg[8 * g + 5] = __builtin_amdgcn_s_memrealtime();
+        if (dbg) a.dbg[16 * g + 5] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     // ---- strips below the diagonal block, shared round-robin by the other workgroups: products with inv(L_cc)
@@ -868,8 +935,9 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
             pa.inv = cp.inv + (size_t)t0 * LEAF * LEAF;
             pa.dinfo = cp.dinfo; pa.goff = off0 + k0;
             pa.flags = c.flags + (size_t)t0 * PFLAG_STRIDE;
-            pa.dbg = g_panel_dbg ? g_panel_dbg + (size_t)8 * t0 : nullptr;
-            hipLaunchKernelGGL(panel_kernel, dim3(pa.G), dim3(LT), 0, sp, pa);
+            pa.dbg = g_panel_dbg ? g_panel_dbg + (size_t)16 * t0 : nullptr;
+            // (at least W workgroups with an id that is a multiple of 8; surplus ones find no ticket and leave)
+            hipLaunchKernelGGL(panel_kernel, dim3(std::max(pa.G, 8 * (pa.W - 1) + 1)), dim3(LT), 0, sp, pa);
             SGPR_CHECK_LAUNCH();
             if (split) return trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
             return 0;
@@ -961,8 +1029,8 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     const bool dbg = PANEL_DBG && getenv("SGPR_PANEL_DBG") != nullptr;
     const int T = (n + LEAF - 1) / LEAF;
     if (dbg) {
-        (void)hipMalloc((void **)&g_panel_dbg, sizeof(unsigned long long) * 8 * T);
-        (void)hipMemset(g_panel_dbg, 0, sizeof(unsigned long long) * 8 * T);
+        (void)hipMalloc((void **)&g_panel_dbg, sizeof(unsigned long long) * 16 * T);
+        (void)hipMemset(g_panel_dbg, 0, sizeof(unsigned long long) * 16 * T);
     }
     int rc;
     if (mode == 2 || (nb_env > 0 && mode == 0 && n > 4 * LEAF && n <= c.la_max))
@@ -971,13 +1039,13 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
         rc = potrf_rec(n, A, lda, 0, c);
     if (dbg) {
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h(8 * (size_t)T);
+        std::vector<unsigned long long> h(16 * (size_t)T);
         (void)hipMemcpy(h.data(), g_panel_dbg, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(g_panel_dbg);
         g_panel_dbg = nullptr;
         std::vector<double> d[6];
         for (int t = 1; t + 1 < T; ++t) {
-            const unsigned long long *p = &h[8 * t], *q = &h[8 * (t + 1)];
+            const unsigned long long *p = &h[16 * t], *q = &h[16 * (t + 1)];
             if (!p[0] || !p[5] || !q[0]) continue;               // first column of a panel: no chain stamps
             d[0].push_back((p[1] - p[0]) * 0.01);                 // E seen -> solve done
             d[1].push_back((p[2] - p[1]) * 0.01);                 // -> F published (at t == 1 entry)
@@ -985,12 +1053,13 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
             d[3].push_back((p[4] - p[3]) * 0.01);                 // -> leaf entered
             d[4].push_back(((double)q[0] - (double)p[4]) * 0.01); // leaf entered -> next strip saw E
             d[5].push_back((p[5] - p[4]) * 0.01);                 // whole leaf incl. inverse + publish
-            d[3].back() = ((double)q[0] - (double)q[2]) * 0.01;   // how long the next strip waited for E
+            d[3].back() = ((double)p[4] - (double)p[1]) * 0.01;   // solve stored -> leaf entered (the update)
+            if (t % 8 == 5) fprintf(stderr, "  col %d: stored->image %.1f, block search %.1f, MFMA %.1f, -> leaf entry %.1f\n", t, (p[8] - p[1]) * 0.01, (p[9] - p[8]) * 0.01, (p[10] - p[9]) * 0.01, ((double)p[4] - (double)p[10]) * 0.01);
             d[1].back() = (p[6] - p[0]) * 0.01;                   // E seen -> L staged
             d[2].back() = (p[7] - p[6]) * 0.01;                   // -> MFMA part done
         }
         auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
-        fprintf(stderr, "panel chain n=%d (%zu columns): E seen -> solve stored %.1f | E seen -> staged %.1f | -> MFMA part done %.1f | (next strip waited for E %.1f) | "
+        fprintf(stderr, "panel chain n=%d (%zu columns): E seen -> solve stored %.1f | E seen -> staged %.1f | -> MFMA part done %.1f | (solve stored -> leaf entry %.1f) | "
                 "leaf entry -> next E seen %.1f | whole leaf %.1f us\n", n, d[0].size(), med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]), med(d[5]));
     }
     return rc;

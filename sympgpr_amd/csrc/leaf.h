@@ -82,6 +82,19 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
         // column j comes from lane j by v_readlane, 1/sqrt by the hardware estimate + two Newton
         // steps, the scaled column is published through a 16-double LDS strip and read back as
         // broadcasts (15 independent reads instead of a chain of dependent cross-lane shuffles).
+        // L goes out to A as its entries become final (write-through when it is handed over early)
+        auto put = [&](double *dst, double v) {
+            if (early_flag) store_wt(dst, v);
+            else *dst = v;
+        };
+        // the factored 16 x 16 diagonal block at c0, two entries per helper thread t < 128, out of LDS
+        auto put_diag = [&](int c0, int t) {
+            const int i = t & 15, c = (t >> 4) * 2;
+            if (c0 + i < nb) {
+                if (c <= i) put(A + (size_t)(c0 + i) + (size_t)(c0 + c) * lda, s[(c0 + c) * LLD + c0 + i]);
+                if (c + 1 <= i) put(A + (size_t)(c0 + i) + (size_t)(c0 + c + 1) * lda, s[(c0 + c + 1) * LLD + c0 + i]);
+            }
+        };
         auto diag_factor = [&](int c0) {
             double a[PW];
 #pragma unroll
@@ -159,6 +172,12 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
                 }
 #pragma unroll
                 for (int c = 0; c < PW; ++c) s[(c0 + c) * LLD + i] = r[c];
+                if (i < nb) {
+#pragma unroll
+                    for (int c = 0; c < PW; ++c) put(A + (size_t)i + (size_t)(c0 + c) * lda, r[c]);
+                }
+            } else if (tid >= LT / 2) {
+                put_diag(c0, tid - LT / 2);            // threads 128.. never have a row here: the diagonal block goes out
             }
             __syncthreads();
             mark(2);
@@ -184,28 +203,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
             __syncthreads();
             mark(3);
         }
-        if (nb == LEAF && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0)) {
-#pragma unroll 8
-            for (int it = 0; it < LEAF * LEAF / (2 * LT); ++it) {
-                const int idx = it * LT + tid;
-                const int i = 2 * (idx % (LEAF / 2)), c = idx / (LEAF / 2);
-                double *dst = A + (size_t)i + (size_t)c * lda;
-                if (early_flag) {
-                    // handed over early: write-through (sc1) stores, so that the flag needs no L2 write-back
-                    if (i >= c) store_wt(dst, s[c * LLD + i]);
-                    if (i + 1 >= c) store_wt(dst + 1, s[c * LLD + i + 1]);
-                } else if (i >= c) {
-                    *reinterpret_cast<double2_t *>(dst) = double2_t{s[c * LLD + i], s[c * LLD + i + 1]};
-                } else if (i + 1 >= c) {
-                    dst[1] = s[c * LLD + i + 1];
-                }
-            }
-        } else {
-            for (int idx = tid; idx < nb * nb; idx += LT) {
-                const int i = idx % nb, c = idx / nb;
-                if (i >= c) A[(size_t)i + (size_t)c * lda] = s[c * LLD + i];
-            }
-        }
+        if (tid >= LT / 2) put_diag(LEAF - PW, tid - LT / 2);
         __syncthreads();
         mark(4);
     }
@@ -217,12 +215,18 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
         const int blk = tid >> 4, c = tid & 15, d0 = blk * PW;
         double x[PW];
         if (tid < 128) {
+            // right-looking substitution: x_k is final after one multiply by 1 / L_kk (all sixteen reciprocals are
+            // independent and go first), and its updates of the later entries are independent of each other
+            double rd[PW];
 #pragma unroll
-            for (int i = 0; i < PW; ++i) {
-                double acc = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < PW; ++k) rd[k] = 1.0 / s[(d0 + k) * LLD + d0 + k];
 #pragma unroll
-                for (int k = 0; k < i; ++k) acc = __builtin_fma(-s[(d0 + k) * LLD + d0 + i], x[k], acc);
-                x[i] = acc / s[(d0 + i) * LLD + d0 + i];
+            for (int i = 0; i < PW; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                x[k] *= rd[k];
+#pragma unroll
+                for (int i = k + 1; i < PW; ++i) x[i] = __builtin_fma(-s[(d0 + k) * LLD + d0 + i], x[k], x[i]);
             }
         }
         __syncthreads();
