@@ -116,17 +116,19 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
             for (int j = 0; j < PW; ++j) {
                 if (!(d > 0.0) && !bad) { bad = true; badj = j; }
                 a[j] = (lane == j) ? d * rl : a[j] * rl;
-                if (lane < PW) sInv[1 + lane] = a[j];
                 if (lane == j) sRl[j] = rl;
                 // the next pivot needs only lane j+1's own values (a[j+1] - a[j]^2): its 1/sqrt chain
-                // runs while column j travels through LDS
+                // runs beside the column update below
                 double dn = 0.0, rn = 0.0;
                 if (j + 1 < PW) pivot(__builtin_fma(-a[j], a[j], a[j + 1]), j + 1, dn, rn);
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // column update a(r,c) -= L(r,j) L(c,j): L(c,j) is a[j] of lane c -- read across the wave into
+                // scalar registers (v_readlane), not through an LDS strip and its write -> wait -> read round trip
 #pragma unroll
-                for (int c = j + 1; c < PW; ++c) a[c] = __builtin_fma(-a[j], sInv[1 + c], a[c]);
-                __builtin_amdgcn_wave_barrier();
+                for (int c = j + 1; c < PW; ++c) {
+                    const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(a[j]), c);
+                    const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(a[j]), c);
+                    a[c] = __builtin_fma(-a[j], __hiloint2double((int)hi, (int)lo), a[c]);
+                }
                 d = dn;
                 rl = rn;
             }
