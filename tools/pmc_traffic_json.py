@@ -37,7 +37,7 @@ out = {"config": {"n_pts": n_pts, "order_n": n, "family": "A", "triangle": "full
        "code_hash": __import__("bench").kernel_code_hash(),
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) of bench.py --steps 1 "
                  "--warmup 0 --cpu-sample 0 --no-launch-events (bench.py itself skips its event pass under the profiler); FETCH_SIZE doubled per the gfx950 note, calibrated on "
-                 "gemv_n; traffic = (2 FETCH + WRITE) KiB * 1024 / launches"}
+                 "trsv_strips_kernel (calibration_trsv_strips below); traffic = (2 FETCH + WRITE) KiB * 1024 / launches"}
 for key, name in (("gemm_nt_kernel<256, 128>", "gemm_nt_kernel<256, 128>"), ("gram_pairs_kernel<0, false, 0>", "gram_pairs_kernel")):
     f, w, c = ft.get(key, 0.0), wt.get(key, 0.0), max(fc.get(key, 0), 1)
     out[name] = {"launches": fc.get(key, 0), "fetch_kb_total": f, "write_kb_total": w,
@@ -49,9 +49,10 @@ g["launches_in_event_run"] = la["big_launches"]
 out["gram_pairs_kernel"]["algorithmic_bytes_per_launch"] = 8.0 * n * n
 # calibration of the FETCH_SIZE doubling on a kernel whose reads are known exactly: the strip solves read L
 # once each (8 n^2 / 2 bytes per launch, two launches per step) with 16-byte loads
-gv = "trsv_strips_kernel"
-if gv in ft:
-    out["calibration_trsv_strips"] = {"launches": fc[gv], "fetch_kb_total_reported": ft[gv],
-                                      "bytes_read_algorithmic_total": 8.0 * n * n / 2 * fc[gv],
-                                      "reported_over_algorithmic": ft[gv] * 1024.0 / (8.0 * n * n / 2 * fc[gv])}
+gvs = [k for k in ft if k.startswith("trsv_strips_kernel")]            # <true> forward, <false> backward
+if gvs:
+    f_tot, launches = sum(ft[k] for k in gvs), sum(fc[k] for k in gvs)
+    out["calibration_trsv_strips"] = {"launches": launches, "fetch_kb_total_reported": f_tot,
+                                      "bytes_read_algorithmic_total": 8.0 * n * n / 2 * launches,
+                                      "reported_over_algorithmic": f_tot * 1024.0 / (8.0 * n * n / 2 * launches)}
 print(json.dumps(out, indent=1))
