@@ -730,3 +730,21 @@ def test_fit_pairs_full_size_configs(oracle, fam, d, N, nrhs):
     if nrhs:
         assert np.all(np.isfinite(Xs))
         assert _oracle_row_residual(oracle, fam, X, idx, hyp, s2, Xs, B) < 1e-10
+
+
+@pytest.mark.parametrize("n,bad", [(1024, 1), (1024, 130), (1024, 257), (1024, 640), (1024, 1024), (2048, 1500), (4096, 3970)])
+def test_not_positive_definite_in_the_panel_kernel(ops, n, bad):
+    """LAPACK's info out of the persistent panel kernel: the first non-positive pivot sits in the first leaf of a
+    panel, in a leaf on the fused chain (solve -> update -> leaf in LDS) and in the last leaf; orders that are
+    multiples of 128, so the look-ahead driver and its panel kernel take them (chol.hip)."""
+    import scipy.linalg.lapack as lp
+    rng = np.random.default_rng(n + bad)
+    B = rng.standard_normal((n, 64))
+    A = B @ B.T + n * np.eye(n)
+    A[bad - 1, bad - 1] = -1.0                 # 1-based minor `bad` is the first that is not positive definite
+    _, info_ref = lp.dpotrf(A, lower=1)
+    assert info_ref == bad
+    with pytest.raises(np.linalg.LinAlgError) as e:
+        ops.cholesky(A)
+    import re
+    assert int(re.search(r"\d+", str(e.value)).group()) == bad
