@@ -41,6 +41,9 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // Rows / columns from nend on are the identity padding: nothing is computed there (a batched fit of order 80
+    // runs 4 of the 7 panel steps).  nb == LEAF is a compile-time constant at the call sites that matter.
+    const int nend = (nb + PW - 1) / PW * PW;
     // diagnostic phase clock (stamps == nullptr in production): cycles per phase, summed over panels
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -156,9 +159,9 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
         if (wave == 0) diag_factor(0);
         __syncthreads();
         mark(1);
-        for (int c0 = 0; c0 < LEAF - PW; c0 += PW) {
+        for (int c0 = 0; c0 < nend - PW; c0 += PW) {
             const int r0 = c0 + PW;
-            const int rem = LEAF - r0;
+            const int rem = nend - r0;
             // ---- (B) panel rows: r := r L11^-T, one row per thread
             if (tid < rem) {
                 const int i = r0 + tid;
@@ -205,7 +208,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
             __syncthreads();
             mark(3);
         }
-        if (tid >= LT / 2) put_diag(LEAF - PW, tid - LT / 2);
+        if (tid >= LT / 2) put_diag(nend - PW, tid - LT / 2);
         __syncthreads();
         mark(4);
     }
@@ -269,6 +272,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
             for (int t = wave; t < ntiles; t += LT / 64) {
                 const int p = t / per, tt = t - p * per, ti = tb - 1 - tt % tb, tj = tt / tb;   // heavy row tiles first
                 const int o = 2 * b * p, o2 = o + b;
+                if (o2 + 16 * ti >= nend) continue;   // rows of the padding: L21 is zero there, and so stays X21
                 const int row = 16 * ti + l15;
                 double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
                 for (int kb = 0; kb < 16 * (ti + 1); kb += 16) {
@@ -293,6 +297,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
             for (int t = wave; t < ntiles; t += LT / 64) {
                 const int p = t / per, tt = t - p * per, ti = tt % tb, tj = tt / tb;
                 const int o = 2 * b * p, o2 = o + b;
+                if (o2 + 16 * ti >= nend) continue;
                 const int col = 16 * tj + l15;
                 double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
                 for (int kb = 16 * tj; kb < b; kb += 16) {
