@@ -169,20 +169,30 @@ __global__ __launch_bounds__(MV_T) void trsv_block_kernel(int n, const double *L
 // launches (leaf, rows-below x inverse, fold into the remaining columns: 60 + 74 + 99 us) on the
 // stream the whole factorisation waits for; here the same tasks run inside ONE grid and hand their
 // results over through flags in global memory:
-//     strip c (its own workgroup):  ... -> leaf(c): factor + invert A(c,c) in LDS        -> I[c]
-//     strip r > c:  wait I[c];  X = A(r,c) inv(L_cc)^T  (a 128^3 product on the matrix cores)
-//                   diagonal strips (r < W) publish X = L(r,c)                           -> F[r][c]
-//                   wait F[c'][c];  A(r,c') -= X L(c',c)^T   for the panel's columns c' in (c, min(W-1, r)]
-//     strip c+1 goes straight from its column-c update to leaf(c+1): the chain the next panel step
-//     waits for is  leaf -> hand-off -> two 128^3 products -> leaf,  with no kernel boundary in it.
-// Workgroups 0..W-1 own the diagonal strips (one each), the others share the strips below round-robin.
+//     diagonal strip g (its own workgroup), columns c = 0 .. g-1:
+//         wait E[c];  X = A(g,c) inv(L_cc)^T by a blocked solve in the MFMA accumulators (trsm_solve: needs L_cc
+//         and its 16 x 16 diagonal inverses only)                                          -> F[g][c]
+//         c < g-1:  A(g,g) -= X X^T out of an LDS image of X;  wait F[c'][c];  A(g,c') -= X L(c',c)^T, c' in (c, g)
+//         c = g-1:  A(g,g) -= X X^T lands in the leaf's LDS block and the strip goes straight on to
+//     leaf(g): factor A(g,g) in LDS, L out write-through as its columns become final,
+//         L + diagonal inverses handed over                                                -> E[g]
+//         full inverse (recursive doubling)                                                -> I[g]
+//     the chain the next panel step waits for is  leaf -> E -> solve -> update -> leaf  inside ONE CU's
+//     registers and LDS per column (~70 us; as three launches per column it was 233 us).
+//     strip r below the diagonal block (shared round-robin by the other workgroups), columns c = 0 .. W-1:
+//         wait I[c];  X = A(r,c) inv(L_cc)^T  (a 128^3 product on the matrix cores);  wait F[c'][c];
+//         A(r,c') -= X L(c',c)^T for c' in (c, W);  on the LAST column: wait E[c] and the blocked solve.
+// Two tickets: diagonal strips go to workgroups whose id is a multiple of 8 (one XCD), in their order of arrival;
+// everybody else, and the leftovers of the first kind, takes the strips below in order of arrival.
 // Hand-off protocol (cdna_hip_programming.md, guideline 16): plain payload stores -> every storing
 // wave drains vmcnt -> workgroup barrier -> one lane: agent-scope release fence, drain, relaxed
-// agent-scope flag store; the consumer polls that word relaxed (one lane, s_sleep between polls),
-// then ONE agent-scope acquire, drain, workgroup barrier, plain loads.
-// Forward progress does not rely on co-residency of the grid: strip ownership follows the ARRIVAL
-// order of the workgroups (a ticket), so every flag a workgroup waits for is set by a workgroup that
-// started before it.  Every spin is bounded; a timeout is reported through *dinfo (PANEL_TIMEOUT).
+// agent-scope flag store (panel_publish); payloads stored write-through (sc1) skip the fence
+// (panel_publish_wt, the leaf's E hand-off).  The consumer polls the word relaxed (one lane, s_sleep between
+// polls), then ONE agent-scope acquire, drain, workgroup barrier, plain loads.
+// Forward progress does not rely on co-residency of the grid: a workgroup only waits for flags of diagonal
+// strips, whose tickets the first eligible workgroups to arrive hold, in order -- every flag a diagonal strip
+// waits for is set by one that started before it.  Every spin is bounded; a timeout is reported through *dinfo
+// (PANEL_TIMEOUT).
 constexpr int PW_MAX = 16;                      // leaf columns per panel (nb <= 2048)
 constexpr int PFLAG_STRIDE = 2 + 2 * PW_MAX + PW_MAX * PW_MAX + 6;   // ints of flag state per panel (296)
 constexpr int PANEL_TIMEOUT = POTRF_HANDOFF_TIMEOUT;   // *dinfo value: a hand-off was never published
@@ -195,7 +205,7 @@ struct PanelArgs {
     double *inv;      // leaf inverses of this panel's W leaves (LEAF x LEAF each)
     int *dinfo;
     int goff;         // global index of the panel's first row / column (LAPACK info)
-    unsigned long long *dbg;   // per-leaf-column time stamps (8 each) or null; written only in -DSGPR_PANEL_DBG builds
+    unsigned long long *dbg;   // per-leaf-column time stamps (16 each) or null; written only in -DSGPR_PANEL_DBG builds
     int *flags;       // PFLAG_STRIDE ints, zero on entry: [0] ticket, [2 + c] I[c], [2 + PW_MAX + c] E[c], [2 + 2 PW_MAX + r * PW_MAX + c] F[r][c]
 };
 
@@ -1054,7 +1064,6 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
             d[4].push_back(((double)q[0] - (double)p[4]) * 0.01); // leaf entered -> next strip saw E
             d[5].push_back((p[5] - p[4]) * 0.01);                 // whole leaf incl. inverse + publish
             d[3].back() = ((double)p[4] - (double)p[1]) * 0.01;   // solve stored -> leaf entered (the update)
-            if (t % 8 == 5) fprintf(stderr, "  col %d: stored->image %.1f, block search %.1f, MFMA %.1f, -> leaf entry %.1f\n", t, (p[8] - p[1]) * 0.01, (p[9] - p[8]) * 0.01, (p[10] - p[9]) * 0.01, ((double)p[4] - (double)p[10]) * 0.01);
             d[1].back() = (p[6] - p[0]) * 0.01;                   // E seen -> L staged
             d[2].back() = (p[7] - p[6]) * 0.01;                   // -> MFMA part done
         }
