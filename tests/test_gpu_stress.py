@@ -94,3 +94,22 @@ def test_two_threads_two_handles(oracle):
         t.join()
     if errs:
         raise errs[0]
+
+
+@pytest.mark.parametrize("n", [640, 768, 896, 1024, 1152, 1280, 1536, 2048, 2560, 3072, 4096, 5120, 6144])
+def test_multiples_of_128_factor_and_solve(n):
+    """orders the persistent panel kernel (fused chain: solve -> update -> leaf in LDS, strips below, split form) and
+    the one-launch strip solves (first strip, one-tile strips, streamed strips) take: L and alpha against LAPACK"""
+    from sympgpr_amd import ops
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n + 5))
+    A = B @ B.T / n + 0.25 * np.eye(n)
+    Lg = ops.cholesky(A)
+    Lr = scipy.linalg.cholesky(A, lower=True)
+    assert np.abs(Lg - Lr).max() <= 1e-11 * np.abs(Lr).max()
+    assert np.all(np.triu(Lg, 1) == 0)
+    b = rng.standard_normal(n)
+    x = ops.solve_cholesky(Lg, b)
+    xr = scipy.linalg.cho_solve((Lr, True), b)
+    assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
+    assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b) * np.linalg.cond(A)
