@@ -34,7 +34,9 @@ __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda,
                                                   unsigned long long *stamps)
 {
     __shared__ double s[LEAF_LDS];
-    leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), nb, A, lda, inv, dinfo, goff, mode, stamps);
+    // a full leaf gets its loop bounds at compile time (59 us; with the run-time order of a partial leaf 64)
+    if (nb == LEAF) leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, A, lda, inv, dinfo, goff, mode, stamps);
+    else            leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), nb, A, lda, inv, dinfo, goff, mode, stamps);
 }
 
 // b(nb) := inv(L) b  or  inv(L)^T b   (inv: LEAF x LEAF lower, zero upper).
@@ -215,7 +217,7 @@ constexpr bool PANEL_DBG = true;
 #else
 constexpr bool PANEL_DBG = false;    // make EXTRA=-DSGPR_PANEL_DBG + SGPR_PANEL_DBG=1: the chain's time stamps per leaf column
 #endif
-static unsigned long long *g_panel_dbg = nullptr;
+static unsigned long long *g_panel_dbg = nullptr;   // debug builds only (one factorisation at a time there); never read otherwise
 
 __device__ __forceinline__ void panel_publish(int *flag)
 {
@@ -945,7 +947,7 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
             pa.inv = cp.inv + (size_t)t0 * LEAF * LEAF;
             pa.dinfo = cp.dinfo; pa.goff = off0 + k0;
             pa.flags = c.flags + (size_t)t0 * PFLAG_STRIDE;
-            pa.dbg = g_panel_dbg ? g_panel_dbg + (size_t)16 * t0 : nullptr;
+            pa.dbg = (PANEL_DBG && g_panel_dbg) ? g_panel_dbg + (size_t)16 * t0 : nullptr;
             // (at least W workgroups with an id that is a multiple of 8; surplus ones find no ticket and leave)
             hipLaunchKernelGGL(panel_kernel, dim3(std::max(pa.G, 8 * (pa.W - 1) + 1)), dim3(LT), 0, sp, pa);
             SGPR_CHECK_LAUNCH();
