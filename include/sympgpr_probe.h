@@ -39,6 +39,30 @@ int sgpr_probe_cumask(const unsigned *mask_words, int nwords, int nblocks, int *
 int sgpr_probe_generated_eval(int family, int which, int m, const double *xa, const double *ya,
                               const double *xb, const double *yb, const double *l, int nl, double *out);
 
+/* The task-queue Cholesky (csrc/cholq.h).  Host only: the ordered task list the worker grid would run for order n
+ * with `nworkers` workers: counts[0] = panels, counts[1] = tasks; starts_out (panels + 1 boundaries) and tasks_out
+ * (packed: [31:30] type 0 = update / 1 = rows-below solve, [29:21] panel, [20:11] row tile of 256, [10:0] column
+ * tile of 128) are filled up to the given capacities.  tests/test_queue_plan.py replays the list on the CPU. */
+int sgpr_probe_queue_plan(int n, int nworkers, int *starts_out, int max_starts, unsigned *tasks_out, int max_tasks,
+                          int *counts);
+/* per-task time stamps of the queue factorisations that follow in this process (4 words per ticket: 100 MHz real
+ * time at ticket drawn / inputs ready / published, then (XCC id << 32) | packed task); _end copies them out and
+ * switches the recording off again.  Behind the 4 * max_tasks ticket words: 2 words per worker workgroup (1024: place
+ * = XCC id << 32 | HW_ID, start) and 4 per workgroup of every panel kernel (512 panels x 32: place, start, end, strip);
+ * `out` holds 4 * max_tasks + 2048 + 65536 words.  Returns the capacity / the number of words copied. */
+int sgpr_probe_queue_trace_begin(int max_tasks);
+int sgpr_probe_queue_trace_end(unsigned long long *out, int max_tasks);
+/* state words of the last task-queue factorisation of this process on stderr (ticket head, abort word, the first
+ * task / panel strip that gave up waiting, version counters); returns the abort word */
+int sgpr_probe_queue_postmortem(int always);
+
+/* co-residency census of two concurrent kernels (A: na workgroups of threads_a threads with lds_a bytes of LDS spinning
+ * spin_a us on one stream, B likewise on a second, high-priority stream; optional CU masks): per workgroup XCC id,
+ * HW_ID, start and end in 100 MHz ticks.  Answers "how many CUs must a persistent grid leave free, and where". */
+int sgpr_probe_census(int na, int threads_a, int lds_a, int spin_a, const unsigned *mask_a, int nwords_a,
+                      int nb, int threads_b, int lds_b, int spin_b, const unsigned *mask_b, int nwords_b,
+                      unsigned long long *host_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,14 @@ PROBE_SIGNATURES = {
     "sgpr_probe_xcc": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "sgpr_probe_hbm_write": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "sgpr_probe_generated_eval": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
+    "sgpr_probe_queue_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint), C.c_int,
+                                        C.POINTER(C.c_int)]),
+    "sgpr_probe_queue_trace_begin": (C.c_int, [C.c_int]),
+    "sgpr_probe_queue_trace_end": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
+    "sgpr_probe_queue_postmortem": (C.c_int, [C.c_int]),
+    "sgpr_probe_census": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,
+                                    C.POINTER(C.c_ulonglong)]),
 }
 
 _LIB = None

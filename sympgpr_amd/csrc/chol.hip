@@ -18,6 +18,7 @@
 #include <mutex>
 #include <vector>
 
+#include "cholq.h"
 #include "common.h"
 #include "gemm_tile.h"
 #include "leaf.h"
@@ -209,6 +210,17 @@ struct PanelArgs {
     int goff;         // global index of the panel's first row / column (LAPACK info)
     unsigned long long *dbg;   // per-leaf-column time stamps (16 each) or null; written only in -DSGPR_PANEL_DBG builds
     int *flags;       // PFLAG_STRIDE ints, zero on entry: [0] ticket, [2 + c] I[c], [2 + PW_MAX + c] E[c], [2 + 2 PW_MAX + r * PW_MAX + c] F[r][c]
+    // task-queue driver (cholq.h): the trailing updates of the earlier panels arrive tile by tile instead of behind a
+    // kernel boundary.  Diagonal strip g starts once its tiles (row tile ver_i0 + g / 2, column tiles ver_j0 .. ver_j0 + g)
+    // carry ver_need updates; `abort` is the queue's give-up word (set here too when a hand-off times out).  Null otherwise.
+    // The strips below the diagonal block (there: the rows of the NEXT diagonal block) wait the same way for their W tiles
+    // and leave tver[tver_r0 + r] = ver_need + 1 behind (strip r of the panel solved against this panel).
+    const int *ver;
+    int ver_ld, ver_i0, ver_j0, ver_need;
+    int *tver;
+    int tver_r0;
+    int *abort;
+    unsigned long long *census;   // diagnostics: 4 words per workgroup (place, start, end, strip), or null
 };
 
 typedef __attribute__((address_space(1))) int gint;
@@ -231,6 +243,18 @@ __device__ __forceinline__ void panel_publish(int *flag)
     }
 }
 
+// ... with a value (the task-queue driver's version words)
+__device__ __forceinline__ void panel_publish_val(int *word, int val)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store((gint *)word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // the same for a payload that went out with write-through (sc1) stores only: no L2 write-back to wait for
 __device__ __forceinline__ void panel_publish_wt(int *flag)
 {
@@ -239,28 +263,46 @@ __device__ __forceinline__ void panel_publish_wt(int *flag)
     if (threadIdx.x == 0) __hip_atomic_store((gint *)flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Wait until every flag in flags[idx[0..cnt)] is set.  Returns false (workgroup-uniform) on timeout.
-__device__ __forceinline__ bool panel_wait(int *flags, const int *idx, int cnt, int *dinfo, int *sh)
+// Wait until every word flags[idx[0..cnt)] has reached `need`.  Returns false (workgroup-uniform) on timeout, or when
+// the task-queue driver has given the factorisation up (`abort` word set; null outside that driver).
+__device__ __forceinline__ bool panel_wait_ge(const int *flags, const int *idx, int cnt, int need, int *dinfo, int *sh,
+                                              int *abort = nullptr)
 {
     if (threadIdx.x == 0) {
         int ok = 1;
         for (int q = 0; q < cnt && ok; ++q) {
             gint *f = (gint *)(flags + idx[q]);
             unsigned spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
-                if (++spins > (3u << 20)) { ok = 0; break; }    // ~ 3 s
+                ++spins;
+                if (abort && (spins & 63u) == 0 && __hip_atomic_load((gint *)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = -1; break; }
+                if (spins > (3u << 20)) { ok = 0; break; }    // ~ 3 s
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!ok) atomicCAS(dinfo, 0, PANEL_TIMEOUT);
-        *sh = ok;
+        if (ok == 0) {
+            atomicCAS(dinfo, 0, PANEL_TIMEOUT);
+            if (abort) {
+                // task-queue driver's post-mortem words (abort = qs + 1): who gave up waiting for what
+                if (atomicCAS(abort + 7, 0, 1) == 0) {
+                    abort[8] = (int)blockIdx.x; abort[9] = idx[0]; abort[10] = cnt; abort[11] = need;
+                    abort[12] = (int)(flags == nullptr);
+                }
+                __hip_atomic_store((gint *)abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        *sh = ok > 0;
     }
     __syncthreads();
     const int ok = *sh;
     __syncthreads();
     return ok != 0;
+}
+__device__ __forceinline__ bool panel_wait(int *flags, const int *idx, int cnt, int *dinfo, int *sh, int *abort = nullptr)
+{
+    return panel_wait_ge(flags, idx, cnt, 1, dinfo, sh, abort);
 }
 
 // C (128 x 128) := beta C + alpha A B^T, k = 128, one workgroup of 256 threads, operands / result in
@@ -537,7 +579,10 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
     // diagonal strips, which the first eligible workgroups to arrive take (the placement is a speed-only assumption).
     if (tid == 0) {
         int t = -1;
-        if ((blockIdx.x & 7) == 0) {
+        // (task-queue driver: the grid is exactly G workgroups on the few CUs the worker grid leaves free, so the diagonal
+        // strips go to the FIRST arrivals whatever their id -- a strip below must never hold a CU that a diagonal strip,
+        // which it waits for, still needs)
+        if ((blockIdx.x & 7) == 0 || a.ver) {
             t = atomicAdd(a.flags, 1);
             if (t >= W) t = -1;
         }
@@ -548,6 +593,13 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
     const int g = sh[0];
     __syncthreads();
     if (g >= G) return;
+    unsigned long long *const cen = (a.census && blockIdx.x < 32) ? a.census + 4 * blockIdx.x : nullptr;
+    if (cen && tid == 0) {
+        cen[0] = ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |
+                 (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        cen[1] = __builtin_amdgcn_s_memrealtime();
+        cen[3] = (unsigned long long)g;
+    }
     const int E0 = 2 + PW_MAX, F0 = 2 + 2 * PW_MAX;
     auto tileptr = [&](int r, int c) { return a.P + (size_t)r * LEAF + (size_t)c * LEAF * a.lda; };
     int idx[PW_MAX];
@@ -555,6 +607,12 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
         // ---- a diagonal strip: row g of the diagonal block, columns 0..g-1, then its own leaf.  Its solves need
         // E[c] only; the last column (c = g - 1) is the chain: solve -> update of (g,g) -> leaf without leaving the CU
         const bool dbg = PANEL_DBG && a.dbg && tid == 0;
+        if (a.ver) {
+            // task-queue driver: this strip's tiles have taken the updates of every earlier panel?
+            const int vi = a.ver_i0 + (g >> 1);
+            for (int c = 0; c <= g; ++c) idx[c] = vi * a.ver_ld + a.ver_j0 + c;
+            if (!panel_wait_ge(a.ver, idx, g + 1, a.ver_need, a.dinfo, sh + 1, a.abort)) return;
+        }
         for (int c = 0; c + 1 < g; ++c) {
             double *X = tileptr(g, c);
             XTile x;
@@ -564,7 +622,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             trsm_prefetch(X, a.lda, x);
             diag_prefetch(tileptr(g, g), a.lda, cd);
             idx[0] = E0 + c;
-            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
             trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
             trsm_store(X, a.lda, x);
             // X = L(g,c) goes to the strips below; the strip's own diagonal tile takes X X^T straight from the
@@ -574,7 +632,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             diag_update_global(s, x, cd, tileptr(g, g), a.lda);
             int cnt = 0;
             for (int cc = c + 1; cc < g; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
-            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1)) return;
+            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return;
             for (int t = 1; t < g - c; ++t)
                 panel_product(s, -1.0, X, a.lda, tileptr(c + t, c), a.lda, 1.0, tileptr(g, c + t), a.lda);
         }
@@ -589,7 +647,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             diag_prefetch(tileptr(g, g), a.lda, cd);
             idx[0] = E0 + c;
             if (dbg) a.dbg[16 * g + 2] = __builtin_amdgcn_s_memrealtime();
-            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
             if (dbg) a.dbg[16 * g + 0] = __builtin_amdgcn_s_memrealtime();
             trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x, a.dbg ? a.dbg + 16 * g + 6 : nullptr);
             trsm_store(X, a.lda, x);
@@ -606,11 +664,18 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
                   a.flags + E0 + g, g > 0);
         panel_publish(a.flags + 2 + g);
         if (dbg) a.dbg[16 * g + 5] = __builtin_amdgcn_s_memrealtime();
+        if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     // ---- strips below the diagonal block, shared round-robin by the other workgroups: products with inv(L_cc)
     const int nw = G - W;
     const int r_first = W + (g - W), r_step = nw > 0 ? nw : R;
+    if (a.ver) {
+        // task-queue driver: one strip per workgroup here; its W tiles carry the updates of every earlier panel?
+        const int vi = a.ver_i0 + (r_first >> 1);
+        for (int c = 0; c < W; ++c) idx[c] = vi * a.ver_ld + a.ver_j0 + c;
+        if (r_first < R && !panel_wait_ge(a.ver, idx, W, a.ver_need, a.dinfo, sh + 1, a.abort)) return;
+    }
     for (int c = 0; c < W; ++c) {
         bool have_inv = false, have_rows = false;
         for (int r = r_first; r < R; r += r_step) {
@@ -624,7 +689,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
                 trsm_prefetch(X, a.lda, x);
                 if (!have_inv) {
                     idx[0] = E0 + c;
-                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
                     have_inv = true;
                 }
                 trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
@@ -633,14 +698,14 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             }
             if (!have_inv) {                           // inv(L_cc) published by strip c's workgroup
                 idx[0] = 2 + c;
-                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1)) return;
+                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
                 have_inv = true;
             }
             for (int t = 0; t <= W - 1 - c; ++t) {     // columns c+1..W-1 of this strip take the update
                 if (t == 1 && !have_rows) {            // ... which needs L(c',c) of the diagonal strips c' in (c, W)
                     int cnt = 0;
                     for (int cc = c + 1; cc < W; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
-                    if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1)) return;
+                    if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return;
                     have_rows = true;
                 }
                 const bool solve = t == 0;
@@ -650,6 +715,8 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             }
         }
     }
+    if (a.tver && r_first < R) panel_publish_val(a.tver + a.tver_r0 + r_first, a.ver_need + 1);
+    if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
 }
 
 inline int split(int n)
@@ -666,6 +733,7 @@ struct Ctx {
     hipStream_t st;
     int la_max = 0;   // potrf_rec hands blocks of order <= la_max to the look-ahead driver (0: never)
     int *flags = nullptr;   // hand-off flags of the panel kernel: PFLAG_STRIDE ints per leaf column, zeroed by potrf()
+    void *qws = nullptr;    // the task-queue driver's part of the workspace (cholq.h), or null
 };
 
 int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0);
@@ -798,7 +866,7 @@ inline size_t flag_bytes(int n)
 
 // [ leaf inverses | hand-off words | two n-vectors the strip solves publish their segments through ]
 inline size_t pub_bytes(int n) { return ((size_t)2 * n * sizeof(double) + 255) / 256 * 256; }
-size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + flag_bytes(n) + pub_bytes(n) + 256; }
+size_t potrf_workspace(int n) { return n <= 0 ? 256 : inv_bytes(n) + flag_bytes(n) + pub_bytes(n) + cholq::ws_bytes(n) + 256; }
 
 namespace {
 
@@ -843,30 +911,172 @@ struct StreamJoin {
     }
 };
 
-int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0)
+// the high-priority side stream of the device that owns the caller's stream (created on first use, one per device)
+int side_stream(hipStream_t caller, hipStream_t *out, int *dev_out)
 {
-    static hipStream_t side[64] = {};          // one side stream per device, created on first use
+    static hipStream_t side[64] = {};
     int dev = -1;
-    if (c.st) {
-        SGPR_HIP(hipStreamGetDevice(c.st, &dev));          // the device that owns the caller's stream
+    if (caller) {
+        SGPR_HIP(hipStreamGetDevice(caller, &dev));        // the device that owns the caller's stream
     } else {
         SGPR_HIP(hipGetDevice(&dev));                      // the null stream belongs to the current device
     }
     if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
-    {
-        static std::mutex mu;                       // two fit handles may factor for the first time at once
-        std::lock_guard<std::mutex> lock(mu);
-        if (!side[dev]) {
-            int cur = -1, lo = 0, hi = 0;
-            SGPR_HIP(hipGetDevice(&cur));
-            if (cur != dev) SGPR_HIP(hipSetDevice(dev));
-            hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-            if (e == hipSuccess) e = hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi);
-            if (cur != dev) (void)hipSetDevice(cur);
-            SGPR_HIP(e);
+    static std::mutex mu;                                  // two fit handles may factor for the first time at once
+    std::lock_guard<std::mutex> lock(mu);
+    if (!side[dev]) {
+        int cur = -1, lo = 0, hi = 0;
+        SGPR_HIP(hipGetDevice(&cur));
+        if (cur != dev) SGPR_HIP(hipSetDevice(dev));
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi);
+        if (cur != dev) (void)hipSetDevice(cur);
+        SGPR_HIP(e);
+    }
+    *out = side[dev];
+    *dev_out = dev;
+    return 0;
+}
+
+// ---- task-queue driver (cholq.h) ----------------------------------------------------------------------------------
+// One persistent worker grid runs every trailing-update tile and every rows-below solve of the block from an ordered
+// task list; the chain of diagonal blocks runs as one panel kernel per panel (diagonal strips + the rows of the next
+// diagonal block) beside it, each strip starting as soon as its own tiles carry the updates of all earlier panels
+// (version counters, no kernel boundary).
+//
+// A panel workgroup (147 KiB of LDS) cannot share a CU with a worker (104 KiB), so the two kernels run on DISJOINT CU
+// SETS: two streams with CU masks (hipExtStreamCreateWithCUMask), R CUs of every XCD for the panel kernels, the rest for
+// the workers.  Merely launching fewer workers than CUs is not enough: the dispatcher binds a workgroup to an XCD and a
+// shader engine round-robin BEFORE it looks for a free CU, and a panel workgroup bound to an engine that the persistent
+// workers fill waits there for good, free CUs next door or not (tools/queue_fail_hunt.py caught it: one panel workgroup
+// started 1.09 s late, on the first CU a worker gave back).  With the masks an engine without a CU of the queue's set is
+// never chosen.  (Mask bit i is CU i / 8 of XCD i % 8: tools/probe_cumask.py.)
+// Queue factorisations of one device are serialised: they share these two streams and their CU sets.
+struct QueueDevice {
+    std::mutex mu;
+    hipEvent_t done = nullptr;                 // end of the last queue factorisation enqueued on this device
+    int ncu = 0;
+    hipStream_t workers[4] = {}, panels[4] = {};   // by R - 1 (CUs per XCD set aside for the panel kernels)
+    bool failed = false;                       // masked streams cannot be had: the look-ahead driver takes over
+};
+QueueDevice g_qdev[64];
+
+int queue_streams(QueueDevice &qd, int dev, int R, hipStream_t *sw, hipStream_t *sp)
+{
+    if (!qd.workers[R - 1]) {
+        int cur = -1;
+        SGPR_HIP(hipGetDevice(&cur));
+        if (cur != dev) SGPR_HIP(hipSetDevice(dev));
+        const int words = qd.ncu / 32;
+        std::vector<uint32_t> mp((size_t)words, 0u), mw((size_t)words, 0xFFFFFFFFu);
+        for (int b = 0; b < 8 * R; ++b) { mp[b / 32] |= 1u << (b % 32); mw[b / 32] &= ~(1u << (b % 32)); }
+        hipError_t e = hipExtStreamCreateWithCUMask(&qd.panels[R - 1], (uint32_t)words, mp.data());
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&qd.workers[R - 1], (uint32_t)words, mw.data());
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            qd.failed = true;
+            return SGPR_E_HIP;
         }
     }
-    const hipStream_t sp = side[dev];
+    *sw = qd.workers[R - 1];
+    *sp = qd.panels[R - 1];
+    return 0;
+}
+
+// returns 1 when the queue form cannot be used here (the caller falls back to the look-ahead driver), < 0 on errors
+int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
+{
+    int dev = -1;
+    if (c.st) {
+        SGPR_HIP(hipStreamGetDevice(c.st, &dev));
+    } else {
+        SGPR_HIP(hipGetDevice(&dev));
+    }
+    if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
+    QueueDevice &qd = g_qdev[dev];
+    std::lock_guard<std::mutex> lock(qd.mu);
+    if (qd.failed) return 1;
+    if (!qd.ncu) {
+        SGPR_HIP(hipDeviceGetAttribute(&qd.ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        SGPR_HIP(hipEventCreateWithFlags(&qd.done, hipEventDisableTiming));
+        SGPR_HIP(hipEventRecord(qd.done, c.st));
+    }
+    if (qd.ncu % 64 != 0 || qd.ncu < 64) { qd.failed = true; return 1; }      // 8 XCDs, whole mask words
+    const std::vector<int> starts = cholq::default_starts(n);
+    int band = 0;       // workgroups of the widest panel kernel: its diagonal strips + the rows of the next diagonal block
+    for (size_t k = 0; k + 1 < starts.size(); ++k)
+        band = std::max(band, (starts[k + 1] - starts[k] + (k + 2 < starts.size() ? starts[k + 2] - starts[k + 1] : 0)) / LEAF);
+    const int R = (band + 7) / 8;
+    if (R > 4) return 1;
+    hipStream_t sw = nullptr, sp = nullptr;
+    if (queue_streams(qd, dev, R, &sw, &sp)) return 1;
+    const int nworkers = qd.ncu - 8 * R;
+    const cholq::Plan *plan = cholq::get_plan(n, nworkers);
+    if (!plan) return SGPR_E_HIP;
+    const cholq::Ws ws = cholq::carve(c.qws, n);
+    const hipStream_t su = c.st;
+    int rc;
+    SGPR_HIP(hipStreamWaitEvent(su, qd.done, 0));               // after the previous queue factorisation on this device
+    if ((rc = cholq::prepare(*plan, ws, su))) return rc;
+    EventSet es;
+    if ((rc = es.create(3))) return rc;
+    const int tn = n / cholq::TN;
+    double *inv_blk = c.inv + (size_t)(off0 / LEAF) * LEAF * LEAF;
+    int *flags_blk = c.flags + (size_t)(off0 / LEAF) * PFLAG_STRIDE;
+    {
+        SGPR_HIP(hipEventRecord(es.ev[0], su));                 // both queue streams join the caller's stream ...
+        SGPR_HIP(hipStreamWaitEvent(sp, es.ev[0], 0));
+        SGPR_HIP(hipStreamWaitEvent(sw, es.ev[0], 0));
+        StreamJoin join_p{sp, su, es.ev[1]};                    // ... and leave it again on every exit path
+        StreamJoin join_w{sw, su, es.ev[2]};
+        for (int k = 0; k < plan->nblk; ++k) {
+            const int k0 = plan->starts[k], w = plan->starts[k + 1] - k0;
+            PanelArgs pa{};
+            pa.P = A + k0 + (size_t)k0 * lda; pa.lda = lda;
+            // the rows of the NEXT diagonal block ride along as strips below (one workgroup each): they sit on the path
+            // panel -> update of the next diagonal block -> next panel
+            const int wnext = k + 1 < plan->nblk ? plan->starts[k + 2] - plan->starts[k + 1] : 0;
+            pa.W = w / LEAF;
+            pa.R = pa.G = (w + wnext) / LEAF;
+            pa.inv = inv_blk + (size_t)(k0 / LEAF) * LEAF * LEAF;
+            pa.dinfo = c.dinfo; pa.goff = off0 + k0;
+            pa.flags = flags_blk + (size_t)(k0 / LEAF) * PFLAG_STRIDE;
+            pa.dbg = nullptr;
+            pa.ver = ws.ver; pa.ver_ld = tn; pa.ver_i0 = k0 / cholq::TM; pa.ver_j0 = k0 / cholq::TN; pa.ver_need = k;
+            pa.tver = ws.tver; pa.tver_r0 = k0 / LEAF;
+            pa.abort = ws.qs + 1;
+            {
+                unsigned long long *cb = cholq::trace_panel_base((int)plan->tasks.size());
+                pa.census = (cb && k < (int)cholq::TRACE_PANELS) ? cb + 4 * cholq::TRACE_PANEL_WGS * (size_t)k : nullptr;
+            }
+            hipLaunchKernelGGL(panel_kernel, dim3(pa.G), dim3(LT), 0, sp, pa);
+            SGPR_CHECK_LAUNCH();
+            if (k == 0 && (rc = cholq::launch_workers(*plan, ws, A, lda, inv_blk, flags_blk, c.dinfo, PFLAG_STRIDE, sw))) return rc;
+        }
+    }
+    SGPR_HIP(hipEventRecord(qd.done, su));
+    cholq::remember(ws, n, (int)plan->tasks.size());          // for the post-mortem probe
+    static const bool qdebug = getenv("SGPR_Q_DEBUG") != nullptr;
+    if (qdebug) {
+        SGPR_HIP(hipStreamSynchronize(su));
+        cholq::postmortem(false);
+    }
+    return 0;
+}
+
+int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0)
+{
+    if (nb == 0 && c.qws && c.flags && cholq::eligible(n) && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0) && off0 % LEAF == 0) {
+        const int rq = potrf_queue(n, A, lda, c, off0);
+        if (rq <= 0) return rq;                 // done, or a real error; 1: not available here
+    }
+    hipStream_t sp = nullptr;
+    {
+        int dev = -1;
+        const int rc0 = side_stream(c.st, &sp, &dev);
+        if (rc0) return rc0;
+    }
     // Panel kernel usable?  (The multi-launch panels below remain for shapes it does not take and for A/B runs.)
     static const int pmode = [] {
         const char *e = getenv("SGPR_LA_PANEL");
@@ -917,7 +1127,7 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
         const int k0 = starts[k], w = starts[k + 1] - k0, rows = n - k0, below = rows - w;
         double *Akk = A + k0 + (size_t)k0 * lda;
         if (fused_ok) {
-            PanelArgs pa;
+            PanelArgs pa{};
             pa.P = Akk; pa.lda = lda;
             pa.R = rows / LEAF; pa.W = w / LEAF;
             const int nbelow = pa.R - pa.W;
@@ -1038,6 +1248,7 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     // (SGPR_LA_MAX overrides; measured crossover of round 1)
     static const int la_max_env = [] { const char *e = getenv("SGPR_LA_MAX"); return e ? atoi(e) : 57344; }();
     Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : la_max_env, flags};
+    if (cholq::ws_bytes(n) > 0) c.qws = static_cast<char *>(work) + inv_bytes(n) + flag_bytes(n) + pub_bytes(n);
     const bool dbg = PANEL_DBG && getenv("SGPR_PANEL_DBG") != nullptr;
     const int T = (n + LEAF - 1) / LEAF;
     if (dbg) {

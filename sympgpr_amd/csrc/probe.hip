@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "cholq.h"
 #include "common.h"
 #include "../../include/sympgpr_probe.h"
 #include "generated/pair_generated.h"
@@ -335,5 +336,96 @@ extern "C" int sgpr_probe_generated_eval(int family, int which, int m, const dou
     SGPR_CHECK_LAUNCH();
     SGPR_HIP(hipMemcpy(out, d[4], sizeof(double) * m, hipMemcpyDeviceToHost));
     for (int k = 0; k < 5; ++k) (void)hipFree(d[k]);
+    return 0;
+}
+
+// ---- task-queue Cholesky diagnostics (cholq.h)
+extern "C" int sgpr_probe_queue_plan(int n, int nworkers, int *starts_out, int max_starts, unsigned *tasks_out,
+                                     int max_tasks, int *counts)
+{
+    cholq::Plan p;
+    const int rc = cholq::build_plan(n, cholq::default_starts(n), nworkers, p);
+    if (rc) return rc;
+    counts[0] = p.nblk;
+    counts[1] = (int)p.tasks.size();
+    for (int k = 0; k <= p.nblk && k < max_starts; ++k) starts_out[k] = p.starts[k];
+    for (size_t t = 0; t < p.tasks.size() && (int)t < max_tasks; ++t) tasks_out[t] = p.tasks[t];
+    return 0;
+}
+
+static unsigned long long *g_qtrace = nullptr;
+static int g_qtrace_cap = 0;
+extern "C" int sgpr_probe_queue_trace_begin(int max_tasks)
+{
+    if (g_qtrace) { cholq::set_trace(nullptr, 0); (void)hipFree(g_qtrace); g_qtrace = nullptr; }
+    SGPR_HIP(hipMalloc((void **)&g_qtrace, sizeof(unsigned long long) * cholq::trace_words((size_t)max_tasks)));
+    SGPR_HIP(hipMemset(g_qtrace, 0, sizeof(unsigned long long) * cholq::trace_words((size_t)max_tasks)));
+    g_qtrace_cap = max_tasks;
+    cholq::set_trace(g_qtrace, (size_t)max_tasks);
+    return max_tasks;
+}
+extern "C" int sgpr_probe_queue_trace_end(unsigned long long *out, int max_tasks)
+{
+    if (!g_qtrace) return 0;
+    SGPR_HIP(hipDeviceSynchronize());
+    cholq::set_trace(nullptr, 0);
+    if (max_tasks < g_qtrace_cap) { set_error("queue_trace_end: buffer smaller than the capacity given to _begin"); return SGPR_E_ARG; }
+    const size_t words = cholq::trace_words((size_t)g_qtrace_cap);
+    SGPR_HIP(hipMemcpy(out, g_qtrace, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost));
+    (void)hipFree(g_qtrace);
+    g_qtrace = nullptr;
+    return (int)words;
+}
+
+extern "C" int sgpr_probe_queue_postmortem(int always) { return cholq::postmortem(always != 0); }
+
+// ---- co-residency census: where and when do the workgroups of two concurrent kernels run?
+// Kernel A (grid na, lds_a bytes of dynamic LDS, spins spin_a us) on one stream, kernel B (nb, lds_b, spin_b) on
+// another, started 50 us later.  out: per workgroup (A first, then B) 4 words: XCC id, HW_ID, start, end (100 MHz
+// real time).  mask_a / mask_b: CU masks of the two streams (nwords = 0: unmasked).
+namespace sgpr { namespace {
+__global__ void census_kernel(unsigned long long *out, int spin_us)
+{
+    extern __shared__ double dyn[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        dyn[0] = 1.0;
+        out[4 * blockIdx.x + 0] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));
+        out[4 * blockIdx.x + 1] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+        out[4 * blockIdx.x + 2] = t0;
+    }
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_us * 100ull) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0) out[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+}
+} }
+extern "C" int sgpr_probe_census(int na, int threads_a, int lds_a, int spin_a, const unsigned *mask_a, int nwords_a,
+                                 int nb, int threads_b, int lds_b, int spin_b, const unsigned *mask_b, int nwords_b,
+                                 unsigned long long *host_out)
+{
+    hipStream_t sa = nullptr, sb = nullptr;
+    if (nwords_a > 0) SGPR_HIP(hipExtStreamCreateWithCUMask(&sa, (uint32_t)nwords_a, mask_a));
+    else              SGPR_HIP(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+    if (nwords_b > 0) SGPR_HIP(hipExtStreamCreateWithCUMask(&sb, (uint32_t)nwords_b, mask_b));
+    else {
+        int lo = 0, hi = 0;
+        SGPR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SGPR_HIP(hipStreamCreateWithPriority(&sb, hipStreamNonBlocking, hi));
+    }
+    unsigned long long *d = nullptr;
+    const size_t words = 4 * (size_t)(na + nb);
+    SGPR_HIP(hipMalloc((void **)&d, sizeof(unsigned long long) * words));
+    SGPR_HIP(hipMemset(d, 0, sizeof(unsigned long long) * words));
+    SGPR_HIP(hipFuncSetAttribute((const void *)sgpr::census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SGPR_HIP(hipDeviceSynchronize());
+    hipLaunchKernelGGL(sgpr::census_kernel, dim3(na), dim3(threads_a), lds_a, sa, d, spin_a);
+    SGPR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sgpr::census_kernel, dim3(nb), dim3(threads_b), lds_b, sb, d + 4 * (size_t)na, spin_b);
+    SGPR_CHECK_LAUNCH();
+    SGPR_HIP(hipStreamSynchronize(sa));
+    SGPR_HIP(hipStreamSynchronize(sb));
+    SGPR_HIP(hipMemcpy(host_out, d, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    (void)hipStreamDestroy(sa);
+    (void)hipStreamDestroy(sb);
     return 0;
 }

@@ -8,7 +8,12 @@ from bench import synth
 for N in [int(a) for a in sys.argv[1:]]:
     q, P, z, hyp, s2 = synth(N)
     with SympFit("A", q, P, z, hyp, s2, lower_only=False) as f:
-        f.run()
+        try:
+            f.run()
+        except Exception:
+            from sympgpr_amd import _lib as L
+            L.load_probe_library().sgpr_probe_queue_postmortem(1)
+            raise
         ts = []
         for _ in range(3):
             f.build(); f.factor(); ts.append(f.stage_ms()[1])
