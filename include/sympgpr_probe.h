@@ -40,18 +40,21 @@ int sgpr_probe_generated_eval(int family, int which, int m, const double *xa, co
                               const double *xb, const double *yb, const double *l, int nl, double *out);
 
 /* The task-queue Cholesky (csrc/cholq.h).  Host only: the ordered task list the worker grid would run for order n
- * with `nworkers` workers: counts[0] = panels, counts[1] = tasks; starts_out (panels + 1 boundaries) and tasks_out
- * (packed: [31:30] type 0 = update / 1 = rows-below solve, [29:21] panel, [20:11] row tile of 256, [10:0] column
- * tile of 128) are filled up to the given capacities.  tests/test_queue_plan.py replays the list on the CPU. */
+ * with `nworkers` workers: counts[0] = panels, counts[1] = tasks, counts[2] = the planner's estimate of the time in
+ * us; starts_out (panels + 1 boundaries) and tasks_out (TWO words per task, cholq.h: word 0 = [31:30] type 0 = update
+ * / 1 = rows-below solve, [29:21] panel, [20:11] row tile of 256, [10:0] column tile of 128; word 1 = [31:16] first,
+ * [15:0] one-past-last 128-column block of L an update applies) are filled up to the given capacities (max_tasks in
+ * tasks).  tests/test_queue_plan.py replays the list on the CPU. */
 int sgpr_probe_queue_plan(int n, int nworkers, int *starts_out, int max_starts, unsigned *tasks_out, int max_tasks,
                           int *counts);
-/* per-task time stamps of the queue factorisations that follow in this process (4 words per ticket: 100 MHz real
- * time at ticket drawn / inputs ready / published, then (XCC id << 32) | packed task); _end copies them out and
- * switches the recording off again.  Behind the 4 * max_tasks ticket words: 2 words per worker workgroup (1024: place
+/* per-task time stamps of the queue factorisations that follow in this process (8 words per ticket: 100 MHz real
+ * time at ticket drawn / inputs ready / published, then task word 1 << 32 | task word 0); _end copies them out and
+ * switches the recording off again.  (words 4..7: ticket of the next task returned, out of the products, stores drained, write-back through.)  Behind the 8 * max_tasks ticket words: 2 words per worker workgroup (1024: place
  * = XCC id << 32 | HW_ID, start) and 4 per workgroup of every panel kernel (512 panels x 32: place, start, end, strip);
- * `out` holds 4 * max_tasks + 2048 + 65536 words.  Returns the capacity / the number of words copied. */
+ * `out` holds 8 * max_tasks + 2048 + 65536 words.  Returns the capacity / the number of words copied. */
 int sgpr_probe_queue_trace_begin(int max_tasks);
 int sgpr_probe_queue_trace_end(unsigned long long *out, int max_tasks);
+int sgpr_probe_queue_trace_clear(void);   /* zero the stamps between two factorisations */
 /* state words of the last task-queue factorisation of this process on stderr (ticket head, abort word, the first
  * task / panel strip that gave up waiting, version counters); returns the abort word */
 int sgpr_probe_queue_postmortem(int always);

@@ -118,6 +118,7 @@ PROBE_SIGNATURES = {
     "sgpr_probe_queue_trace_begin": (C.c_int, [C.c_int]),
     "sgpr_probe_queue_trace_end": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sgpr_probe_queue_postmortem": (C.c_int, [C.c_int]),
+    "sgpr_probe_queue_trace_clear": (C.c_int, []),
     "sgpr_probe_census": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,
                                     C.POINTER(C.c_ulonglong)]),

@@ -218,7 +218,7 @@ struct PanelArgs {
     const int *ver;
     int ver_ld, ver_i0, ver_j0, ver_need;
     int *tver;
-    int tver_r0;
+    int tver_r0, tver_val;
     int *abort;
     unsigned long long *census;   // diagnostics: 4 words per workgroup (place, start, end, strip), or null
 };
@@ -273,11 +273,20 @@ __device__ __forceinline__ bool panel_wait_ge(const int *flags, const int *idx, 
         for (int q = 0; q < cnt && ok; ++q) {
             gint *f = (gint *)(flags + idx[q]);
             unsigned spins = 0;
+            const unsigned long long twait0 = abort ? __builtin_amdgcn_s_memrealtime() : 0;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
                 __builtin_amdgcn_s_sleep(16);
                 ++spins;
-                if (abort && (spins & 63u) == 0 && __hip_atomic_load((gint *)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = -1; break; }
-                if (spins > (3u << 20)) { ok = 0; break; }    // ~ 3 s
+                if (abort) {
+                    // task-queue driver: a long wait backs off to one look every ~7 us (hundreds of waiters polling a handful
+                    // of words flat out starve the loads of the workgroups they wait for: cholq.hip), and gives up when the
+                    // workers have, or after 20 s of REAL time
+                    if (spins > 16) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+                    if ((spins & 15u) == 0) {
+                        if (__hip_atomic_load((gint *)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = -1; break; }
+                        if (__builtin_amdgcn_s_memrealtime() - twait0 > 20ull * 100000000ull) { ok = 0; break; }
+                    }
+                } else if (spins > (3u << 20)) { ok = 0; break; }    // ~ 3 s
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -285,7 +294,7 @@ __device__ __forceinline__ bool panel_wait_ge(const int *flags, const int *idx, 
         if (ok == 0) {
             atomicCAS(dinfo, 0, PANEL_TIMEOUT);
             if (abort) {
-                // task-queue driver's post-mortem words (abort = qs + 1): who gave up waiting for what
+                // task-queue driver's post-mortem words (abort = qs + Q_ABORT): who gave up waiting for what
                 if (atomicCAS(abort + 7, 0, 1) == 0) {
                     abort[8] = (int)blockIdx.x; abort[9] = idx[0]; abort[10] = cnt; abort[11] = need;
                     abort[12] = (int)(flags == nullptr);
@@ -565,34 +574,12 @@ __device__ __forceinline__ void diag_update_global(double *s, const XTile &x, CT
     }
 }
 
-__global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
+// One strip of one panel (g < W: diagonal strip g; otherwise a strip below the diagonal block).  False: a hand-off timed
+// out or the factorisation has been given up.  `s`: LEAF * ILD doubles of LDS, `sh`: two ints.
+__device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, double *s, int *sh)
 {
-    __shared__ double s[LEAF * ILD];   // the leaf's 128 x 130 block / the chain's 128 x 144 images; the products stage through its first 72 KiB
-    __shared__ int sh[2];
-    static_assert(2 * tile::BK * 2 * (LEAF + tile::PAD) <= LEAF_LDS && LEAF_LDS <= LEAF * ILD, "product staging and the leaf fit the buffer");
     const int tid = threadIdx.x;
     const int W = a.W, R = a.R, G = a.G;
-    // Two tickets.  The diagonal strips -- the chain -- go to workgroups whose id is a multiple of 8, i.e. (with the
-    // dispatcher's round-robin) to ONE XCD, so that what a leaf hands to the next strip is found in that XCD's L2
-    // and not in memory; the strips below go to everybody else, and to the leftovers of the first kind.  Arrival
-    // order within each kind: a workgroup still only waits for flags of workgroups that started before it or of
-    // diagonal strips, which the first eligible workgroups to arrive take (the placement is a speed-only assumption).
-    if (tid == 0) {
-        int t = -1;
-        // (task-queue driver: the grid is exactly G workgroups on the few CUs the worker grid leaves free, so the diagonal
-        // strips go to the FIRST arrivals whatever their id -- a strip below must never hold a CU that a diagonal strip,
-        // which it waits for, still needs)
-        if ((blockIdx.x & 7) == 0 || a.ver) {
-            t = atomicAdd(a.flags, 1);
-            if (t >= W) t = -1;
-        }
-        if (t < 0) t = W + atomicAdd(a.flags + 1, 1);
-        sh[0] = t;
-    }
-    __syncthreads();
-    const int g = sh[0];
-    __syncthreads();
-    if (g >= G) return;
     unsigned long long *const cen = (a.census && blockIdx.x < 32) ? a.census + 4 * blockIdx.x : nullptr;
     if (cen && tid == 0) {
         cen[0] = ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |
@@ -610,8 +597,8 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
         if (a.ver) {
             // task-queue driver: this strip's tiles have taken the updates of every earlier panel?
             const int vi = a.ver_i0 + (g >> 1);
-            for (int c = 0; c <= g; ++c) idx[c] = vi * a.ver_ld + a.ver_j0 + c;
-            if (!panel_wait_ge(a.ver, idx, g + 1, a.ver_need, a.dinfo, sh + 1, a.abort)) return;
+            for (int c = 0; c <= g; ++c) idx[c] = (vi * a.ver_ld + a.ver_j0 + c) * (int)cholq::VS;
+            if (!panel_wait_ge(a.ver, idx, g + 1, a.ver_need, a.dinfo, sh + 1, a.abort)) return false;
         }
         for (int c = 0; c + 1 < g; ++c) {
             double *X = tileptr(g, c);
@@ -622,7 +609,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             trsm_prefetch(X, a.lda, x);
             diag_prefetch(tileptr(g, g), a.lda, cd);
             idx[0] = E0 + c;
-            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
+            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
             trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
             trsm_store(X, a.lda, x);
             // X = L(g,c) goes to the strips below; the strip's own diagonal tile takes X X^T straight from the
@@ -632,7 +619,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             diag_update_global(s, x, cd, tileptr(g, g), a.lda);
             int cnt = 0;
             for (int cc = c + 1; cc < g; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
-            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return;
+            if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return false;
             for (int t = 1; t < g - c; ++t)
                 panel_product(s, -1.0, X, a.lda, tileptr(c + t, c), a.lda, 1.0, tileptr(g, c + t), a.lda);
         }
@@ -647,7 +634,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             diag_prefetch(tileptr(g, g), a.lda, cd);
             idx[0] = E0 + c;
             if (dbg) a.dbg[16 * g + 2] = __builtin_amdgcn_s_memrealtime();
-            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
+            if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
             if (dbg) a.dbg[16 * g + 0] = __builtin_amdgcn_s_memrealtime();
             trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x, a.dbg ? a.dbg + 16 * g + 6 : nullptr);
             trsm_store(X, a.lda, x);
@@ -665,7 +652,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
         panel_publish(a.flags + 2 + g);
         if (dbg) a.dbg[16 * g + 5] = __builtin_amdgcn_s_memrealtime();
         if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
-        return;
+        return true;
     }
     // ---- strips below the diagonal block, shared round-robin by the other workgroups: products with inv(L_cc)
     const int nw = G - W;
@@ -673,8 +660,8 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
     if (a.ver) {
         // task-queue driver: one strip per workgroup here; its W tiles carry the updates of every earlier panel?
         const int vi = a.ver_i0 + (r_first >> 1);
-        for (int c = 0; c < W; ++c) idx[c] = vi * a.ver_ld + a.ver_j0 + c;
-        if (r_first < R && !panel_wait_ge(a.ver, idx, W, a.ver_need, a.dinfo, sh + 1, a.abort)) return;
+        for (int c = 0; c < W; ++c) idx[c] = (vi * a.ver_ld + a.ver_j0 + c) * (int)cholq::VS;
+        if (r_first < R && !panel_wait_ge(a.ver, idx, W, a.ver_need, a.dinfo, sh + 1, a.abort)) return false;
     }
     for (int c = 0; c < W; ++c) {
         bool have_inv = false, have_rows = false;
@@ -689,7 +676,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
                 trsm_prefetch(X, a.lda, x);
                 if (!have_inv) {
                     idx[0] = E0 + c;
-                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
+                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
                     have_inv = true;
                 }
                 trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
@@ -698,14 +685,14 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             }
             if (!have_inv) {                           // inv(L_cc) published by strip c's workgroup
                 idx[0] = 2 + c;
-                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return;
+                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
                 have_inv = true;
             }
             for (int t = 0; t <= W - 1 - c; ++t) {     // columns c+1..W-1 of this strip take the update
                 if (t == 1 && !have_rows) {            // ... which needs L(c',c) of the diagonal strips c' in (c, W)
                     int cnt = 0;
                     for (int cc = c + 1; cc < W; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
-                    if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return;
+                    if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return false;
                     have_rows = true;
                 }
                 const bool solve = t == 0;
@@ -715,8 +702,83 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
             }
         }
     }
-    if (a.tver && r_first < R) panel_publish_val(a.tver + a.tver_r0 + r_first, a.ver_need + 1);
+    if (a.tver && r_first < R) panel_publish_val(a.tver + (size_t)(a.tver_r0 + r_first) * cholq::VS, a.tver_val);
     if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
+    return true;
+}
+
+__global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
+{
+    __shared__ double s[LEAF * ILD];   // the leaf's 128 x 130 block / the chain's 128 x 144 images; the products stage through its first 72 KiB
+    __shared__ int sh[2];
+    static_assert(2 * tile::BK * 2 * (LEAF + tile::PAD) <= LEAF_LDS && LEAF_LDS <= LEAF * ILD, "product staging and the leaf fit the buffer");
+    const int tid = threadIdx.x;
+    const int W = a.W, G = a.G;
+    // Two tickets.  The diagonal strips -- the chain -- go to workgroups whose id is a multiple of 8, i.e. (with the
+    // dispatcher's round-robin) to ONE XCD, so that what a leaf hands to the next strip is found in that XCD's L2
+    // and not in memory; the strips below go to everybody else, and to the leftovers of the first kind.  Arrival
+    // order within each kind: a workgroup still only waits for flags of workgroups that started before it or of
+    // diagonal strips, which the first eligible workgroups to arrive take (the placement is a speed-only assumption).
+    if (tid == 0) {
+        int t = -1;
+        if ((blockIdx.x & 7) == 0) {
+            t = atomicAdd(a.flags, 1);
+            if (t >= W) t = -1;
+        }
+        if (t < 0) t = W + atomicAdd(a.flags + 1, 1);
+        sh[0] = t;
+    }
+    __syncthreads();
+    const int g = sh[0];
+    __syncthreads();
+    if (g >= G) return;
+    (void)panel_strip(a, g, s, sh);
+}
+
+// The task-queue driver's form (cholq.h): ONE launch walks all panels of the block.  Workgroup b is strip b of every
+// panel -- diagonal strip b while b < W, else row strip b - W of the next diagonal block -- and goes from one panel to the
+// next without a kernel boundary: what it waits for are the version counters of its tiles.  (One launch per panel put 31
+// command-processor dispatches on the path every worker spins on, and once in a few hundred factorisations one of them
+// came 1.5 s late: tools/queue_stress.py.)
+struct PanelSeq {
+    double *A;              // origin of the block being factored
+    size_t lda;
+    int nblk;
+    const int *pstart;      // nblk + 1 panel boundaries (device)
+    double *inv;            // leaf inverses of the block
+    int *dinfo;
+    int goff;               // global index of the block's first row (LAPACK info)
+    int *flags;             // hand-off words of the block: panel starting at leaf column t at flags + t * PFLAG_STRIDE
+    const int *ver;
+    int ver_ld;
+    int *tver;
+    int *abort;
+    unsigned long long *census;
+};
+
+__global__ __launch_bounds__(LT) void panel_seq_kernel(const PanelSeq q)
+{
+    __shared__ double s[LEAF * ILD];
+    __shared__ int sh[2];
+    const int g = blockIdx.x;
+    for (int k = 0; k < q.nblk; ++k) {
+        const int k0 = q.pstart[k], w = q.pstart[k + 1] - k0, wnext = k + 1 < q.nblk ? q.pstart[k + 2] - q.pstart[k + 1] : 0;
+        PanelArgs a{};
+        a.P = q.A + k0 + (size_t)k0 * q.lda; a.lda = q.lda;
+        a.W = w / LEAF;
+        a.R = a.G = (w + wnext) / LEAF;
+        a.inv = q.inv + (size_t)(k0 / LEAF) * LEAF * LEAF;
+        a.dinfo = q.dinfo; a.goff = q.goff + k0;
+        a.flags = q.flags + (size_t)(k0 / LEAF) * PFLAG_STRIDE;
+        a.dbg = nullptr;
+        a.ver = q.ver; a.ver_ld = q.ver_ld; a.ver_i0 = k0 / cholq::TM; a.ver_j0 = k0 / cholq::TN; a.ver_need = k0 / LEAF;
+        a.tver = q.tver; a.tver_r0 = k0 / LEAF; a.tver_val = (k0 + w) / LEAF;
+        a.abort = q.abort;
+        a.census = (q.census && k < (int)cholq::TRACE_PANELS) ? q.census + 4 * cholq::TRACE_PANEL_WGS * (size_t)k : nullptr;
+        if (g < a.G && !panel_strip(a, g, s, sh)) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 }
 
 inline int split(int n)
@@ -1013,7 +1075,7 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     if (queue_streams(qd, dev, R, &sw, &sp)) return 1;
     const int nworkers = qd.ncu - 8 * R;
     const cholq::Plan *plan = cholq::get_plan(n, nworkers);
-    if (!plan) return SGPR_E_HIP;
+    if (!plan) return 1;
     const cholq::Ws ws = cholq::carve(c.qws, n);
     const hipStream_t su = c.st;
     int rc;
@@ -1030,33 +1092,18 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         SGPR_HIP(hipStreamWaitEvent(sw, es.ev[0], 0));
         StreamJoin join_p{sp, su, es.ev[1]};                    // ... and leave it again on every exit path
         StreamJoin join_w{sw, su, es.ev[2]};
-        for (int k = 0; k < plan->nblk; ++k) {
-            const int k0 = plan->starts[k], w = plan->starts[k + 1] - k0;
-            PanelArgs pa{};
-            pa.P = A + k0 + (size_t)k0 * lda; pa.lda = lda;
-            // the rows of the NEXT diagonal block ride along as strips below (one workgroup each): they sit on the path
-            // panel -> update of the next diagonal block -> next panel
-            const int wnext = k + 1 < plan->nblk ? plan->starts[k + 2] - plan->starts[k + 1] : 0;
-            pa.W = w / LEAF;
-            pa.R = pa.G = (w + wnext) / LEAF;
-            pa.inv = inv_blk + (size_t)(k0 / LEAF) * LEAF * LEAF;
-            pa.dinfo = c.dinfo; pa.goff = off0 + k0;
-            pa.flags = flags_blk + (size_t)(k0 / LEAF) * PFLAG_STRIDE;
-            pa.dbg = nullptr;
-            pa.ver = ws.ver; pa.ver_ld = tn; pa.ver_i0 = k0 / cholq::TM; pa.ver_j0 = k0 / cholq::TN; pa.ver_need = k;
-            pa.tver = ws.tver; pa.tver_r0 = k0 / LEAF;
-            pa.abort = ws.qs + 1;
-            {
-                unsigned long long *cb = cholq::trace_panel_base((int)plan->tasks.size());
-                pa.census = (cb && k < (int)cholq::TRACE_PANELS) ? cb + 4 * cholq::TRACE_PANEL_WGS * (size_t)k : nullptr;
-            }
-            hipLaunchKernelGGL(panel_kernel, dim3(pa.G), dim3(LT), 0, sp, pa);
-            SGPR_CHECK_LAUNCH();
-            if (k == 0 && (rc = cholq::launch_workers(*plan, ws, A, lda, inv_blk, flags_blk, c.dinfo, PFLAG_STRIDE, sw))) return rc;
-        }
+        PanelSeq ps{};
+        ps.A = A; ps.lda = lda; ps.nblk = plan->nblk; ps.pstart = ws.pstart;
+        ps.inv = inv_blk; ps.dinfo = c.dinfo; ps.goff = off0; ps.flags = flags_blk;
+        ps.ver = ws.ver; ps.ver_ld = tn; ps.tver = ws.tver; ps.abort = cholq::abort_word(ws);
+        ps.census = cholq::trace_panel_base((int)(plan->tasks.size() / 2));
+        hipLaunchKernelGGL(panel_seq_kernel, dim3(band), dim3(LT), 0, sp, ps);
+        SGPR_CHECK_LAUNCH();
+        if ((rc = cholq::launch_workers(*plan, ws, A, lda, inv_blk, flags_blk, c.dinfo, PFLAG_STRIDE, sw))) return rc;
     }
     SGPR_HIP(hipEventRecord(qd.done, su));
-    cholq::remember(ws, n, (int)plan->tasks.size());          // for the post-mortem probe
+    cholq::remember(ws, n, (int)(plan->tasks.size() / 2));
+    cholq::remember_plan(plan);          // for the post-mortem probe
     static const bool qdebug = getenv("SGPR_Q_DEBUG") != nullptr;
     if (qdebug) {
         SGPR_HIP(hipStreamSynchronize(su));

@@ -21,11 +21,14 @@ namespace cholq {
 constexpr int TM = 256, TN = 128;          // the workers' tile of the trailing matrix
 enum { TASK_U = 0, TASK_T = 1 };
 
-// One task, packed: [31:30] type, [29:21] panel k, [20:11] row tile i (256 rows), [10:0] column tile j (128 columns)
-//   U(k, i, j): C(i, j) -= L(i, panel k) L(j, panel k)^T        needs tver[2i], tver[2i+1], tver[j] > k, ver[i][j] == k
-//   T(k, i)   : A(i, panel k) := A(i, panel k) L_kk^-T          needs ver[i][columns of panel k] == k, the panel's leaves
-// (ver: updates applied per tile; tver: panels solved per 128-row strip.  The rows of the NEXT diagonal block have no
-// T task: the panel kernel solves them beside its chain and bumps their tver itself.)
+// One task = two words.  Word 0: [31:30] type, [29:21] panel k (solves), [20:11] row tile i (256 rows), [10:0] column
+// tile j (128 columns); word 1 (updates): [31:16] a, [15:0] b in units of 128 columns.
+//   U(i, j, a, b): C(i, j) -= L(i, a:b) L(j, a:b)^T     needs ver[i][j] >= a, tver[2i], tver[2i+1], tver[j] >= b; leaves ver[i][j] = b
+//   T(k, i)      : A(i, panel k) := A(i, panel k) L_kk^-T   needs ver[i][columns of panel k] >= start of panel k, the
+//                  panel's leaves inverted; leaves tver[2i] = tver[2i+1] = end of panel k
+// ver[i][j]: leading 128-column blocks of L already applied to tile (i, j); tver[r]: leading blocks of row strip r (128
+// rows) that are final.  The rows of the NEXT diagonal block have no T task: the panel kernel solves them beside its
+// chain and sets their tver itself.
 inline unsigned pack(int type, int k, int i, int j) { return ((unsigned)type << 30) | ((unsigned)k << 21) | ((unsigned)i << 11) | (unsigned)j; }
 inline int task_type(unsigned t) { return (int)(t >> 30); }
 inline int task_k(unsigned t) { return (int)((t >> 21) & 511u); }
@@ -36,8 +39,9 @@ constexpr int MAX_ORDER = 131072;          // 9-bit panel index at >= 256 column
 struct Plan {
     int n = 0, nblk = 0, wmax = 0, nworkers = 0;
     std::vector<int> starts;               // nblk + 1 panel boundaries (multiples of 256)
-    std::vector<unsigned> tasks;           // in ticket order: every dependency of a task has a smaller ticket
+    std::vector<unsigned> tasks;           // two words per task, in ticket order: every input of a task comes from a smaller ticket
     double flop = 0.0;                     // algorithmic flop of the tasks (2k per updated element on / below the diagonal)
+    double model_us = 0.0;                 // the planner's own estimate of the factorisation time
     unsigned *pinned = nullptr;            // page-locked copy for the upload: [starts | tasks]
 };
 
@@ -50,12 +54,21 @@ const Plan *get_plan(int n, int nworkers);
 
 // bytes of the queue's part of the factor workspace for order n (0: the queue form is not used for this order)
 size_t ws_bytes(int n);
+size_t max_tasks(int n);
 bool eligible(int n);
 
+// The ticket head is hit by a returning atomic from every workgroup at every task; the give-up word is READ by every
+// waiting workgroup.  On one cache line the readers starved the atomics: once in a few hundred factorisations a few
+// workgroups stood for as long as everybody else waited -- for them (tools/queue_stress.py).  So: a line of its own.
+constexpr int Q_ABORT = 32;
+// ... and every version word too: VS ints apart = one 128-byte line per word.  Packed, the 128 words that say how far
+// each row strip is solved sat on four lines that every waiting workgroup of the chip polled.
+constexpr size_t VS = 32;                // qs[32..63]: give-up word + the panel kernel's post-mortem words
+
 struct Ws {                                // pointers into the queue's part of the workspace
-    int *qs;                               // [0] ticket head, [1] abort, [2..] spare
-    int *ver;                              // tm x tn update counts per tile
-    int *tver;                             // tn: panels solved per 128-row strip
+    int *qs;                               // 64 ints: [0] ticket head, [2..7] post-mortem of the worker that gave up, [Q_ABORT] give-up word
+    int *ver;                              // tm x tn words (VS ints apart): leading 128-column blocks of L applied to tile (i, j)
+    int *tver;                             // tn words (VS ints apart): leading blocks final per 128-row strip
     int *pstart;                           // nblk + 1
     unsigned *tasks;
     size_t zero_bytes;                     // qs .. tver: cleared before every factorisation
@@ -70,14 +83,18 @@ int launch_workers(const Plan &p, const Ws &w, double *A, size_t lda, const doub
 // diagnostics: the last queue workspace used by this process, and a dump of its state words (head, abort, the
 // first task / panel strip that gave up, tver, the ver map) to stderr; `always` = also when nothing gave up
 void remember(const Ws &w, int n, int ntasks);
+void remember_plan(const Plan *p);
 int postmortem(bool always);
+int *abort_word(const Ws &w);
 
 // diagnostics (libsympgpr_probe.so): per-task time stamps of the next factorisation(s) in this process
 void set_trace(unsigned long long *dev_buf, size_t capacity_tasks);
-// layout of the trace buffer: 4 words per ticket, then 2 per worker workgroup (place, start), then 4 per workgroup of
-// every panel kernel (place, start, end, strip), 32 workgroups per panel
+// layout of the trace buffer: 8 words per ticket (free, inputs there, published, task words, ticket returned, out of the
+// products, stores drained, write-back through), then 2 per worker workgroup (place, start), then 4 per workgroup of every
+// panel (place, start, end, strip), 32 workgroups per panel
 constexpr size_t TRACE_WORKERS = 1024, TRACE_PANELS = 512, TRACE_PANEL_WGS = 32;
-inline size_t trace_words(size_t cap) { return 4 * cap + 2 * TRACE_WORKERS + 4 * TRACE_PANELS * TRACE_PANEL_WGS; }
+constexpr size_t TRACE_STRIDE = 8;
+inline size_t trace_words(size_t cap) { return TRACE_STRIDE * cap + 2 * TRACE_WORKERS + 4 * TRACE_PANELS * TRACE_PANEL_WGS; }
 unsigned long long *trace_panel_base(int ntasks);   // null when no trace is being taken
 
 }  // namespace cholq

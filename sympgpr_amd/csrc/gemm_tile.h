@@ -43,6 +43,7 @@ struct GemmArgs {
     // single GPU: lblk = 1, lpr = lpc = 1, lpi = diag_off, lpj = 0  (row + diag_off >= col)
     int lblk, lpr, lpi, lpc, lpj;
     int dbg;  // probe switches: 8 = force the 128x128 tile shape, 16 = force the register-staged body
+    unsigned long long *kdone;  // diagnostic (task-queue trace): 100 MHz time at which wave 0 left the k-loop, or null
 };
 
 // Workgroup -> tile map.  The dispatcher deals consecutive workgroup ids round-robin over the 8
@@ -550,6 +551,7 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
         o[0] = st_c0; o[1] = __builtin_amdgcn_s_memtime();
         o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
     }
+    if (g.kdone && tid == 0) *g.kdone = __builtin_amdgcn_s_memrealtime();
 
     // interior tile: no bounds checks.  acc[i][j][r] is C(row0 + wm*64 + j*16 + l15, col0 + wn*64 + i*16 + 4r + l4)
     // The old values of C are fetched 16 at a time BEFORE any of them is overwritten: written as

@@ -347,9 +347,10 @@ extern "C" int sgpr_probe_queue_plan(int n, int nworkers, int *starts_out, int m
     const int rc = cholq::build_plan(n, cholq::default_starts(n), nworkers, p);
     if (rc) return rc;
     counts[0] = p.nblk;
-    counts[1] = (int)p.tasks.size();
+    counts[1] = (int)(p.tasks.size() / 2);
+    counts[2] = (int)p.model_us;
     for (int k = 0; k <= p.nblk && k < max_starts; ++k) starts_out[k] = p.starts[k];
-    for (size_t t = 0; t < p.tasks.size() && (int)t < max_tasks; ++t) tasks_out[t] = p.tasks[t];
+    for (size_t t = 0; t < p.tasks.size() && (int)(t / 2) < max_tasks; ++t) tasks_out[t] = p.tasks[t];
     return 0;
 }
 
@@ -363,6 +364,12 @@ extern "C" int sgpr_probe_queue_trace_begin(int max_tasks)
     g_qtrace_cap = max_tasks;
     cholq::set_trace(g_qtrace, (size_t)max_tasks);
     return max_tasks;
+}
+extern "C" int sgpr_probe_queue_trace_clear()
+{
+    if (!g_qtrace) return 0;
+    SGPR_HIP(hipMemset(g_qtrace, 0, sizeof(unsigned long long) * cholq::trace_words((size_t)g_qtrace_cap)));
+    return 0;
 }
 extern "C" int sgpr_probe_queue_trace_end(unsigned long long *out, int max_tasks)
 {

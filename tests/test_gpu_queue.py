@@ -1,0 +1,49 @@
+"""The task-queue Cholesky (opt-in: SGPR_POTRF_Q=1, read once per process, so the checks run in a child process)
+against SciPy through the host entry point, sgpr_potrf_host = scipy.linalg.cholesky(lower=True) of
+python/functions/func.py:166,184,193."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GIVE_UP = "a hand-off inside the panel kernel timed out"
+
+
+def run_check(sizes, extra_env=None):
+    env = dict(os.environ, SGPR_POTRF_Q="1", SGPR_Q_MIN="2048")
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "queue_check.py")] + [str(s) for s in sizes],
+                          env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_queue_factor_vs_scipy():
+    sizes = [2048, 2304, 4096, 6144, 12288]
+    r = run_check(sizes)
+    if r.returncode != 0 and GIVE_UP in (r.stdout + r.stderr):
+        # the documented intermittent give-up of the opt-in path: an error after a bounded wait, never
+        # a wrong factor.  One more go; a wrong result or a second give-up fails the test.
+        r = run_check(sizes)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok") == len(sizes), r.stdout
+
+
+def test_queue_not_positive_definite_reports_lapack_info():
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from sympgpr_amd import ops\n"
+        "n, bad = 4096, 2900\n"
+        "rng = np.random.default_rng(3)\n"
+        "B = rng.standard_normal((n, n + 3)); A = B @ B.T / n + 0.5 * np.eye(n)\n"
+        "A[bad, bad] = -1.0\n"
+        "try:\n"
+        "    ops.cholesky(A)\n"
+        "    print('NO ERROR')\n"
+        "except np.linalg.LinAlgError as e:\n"
+        "    print('LinAlgError', str(e))\n" % ROOT)
+    env = dict(os.environ, SGPR_POTRF_Q="1", SGPR_Q_MIN="2048")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "LinAlgError %d-th leading minor" % 2901 in r.stdout, r.stdout[-1000:] + r.stderr[-1000:]

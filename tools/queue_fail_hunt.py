@@ -7,7 +7,7 @@ from sympgpr_amd.fit import SympFit
 from bench import synth
 probe = L.load_probe_library()
 cap = 1 << 16
-nwords = 4 * cap + 2048 + 65536
+nwords = 8 * cap + 2048 + 65536
 buf = (C.c_ulonglong * nwords)()
 assert probe.sgpr_probe_queue_trace_begin(cap) == cap
 failed = None
@@ -24,8 +24,8 @@ for N in [int(a) for a in sys.argv[1:]]:
         break
 probe.sgpr_probe_queue_trace_end(buf, cap)
 allw = np.frombuffer(buf, dtype=np.uint64, count=nwords)
-wc = allw[4 * cap:4 * cap + 2048].reshape(-1, 2)
-pc = allw[4 * cap + 2048:].reshape(512, 32, 4)
+wc = allw[8 * cap:8 * cap + 2048].reshape(-1, 2)
+pc = allw[8 * cap + 2048:].reshape(512, 32, 4)
 wc = wc[wc[:, 1] != 0]
 t0 = int(wc[:, 1].min())
 def place(x):

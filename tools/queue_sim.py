@@ -1,9 +1,7 @@
 """The task-queue Cholesky's plan (csrc/cholq.h) on the CPU: fetch the ordered task list from the library (host code,
 no GPU needed), check its ordering invariant, replay it numerically with NumPy, and run it through a discrete-event
-model of the worker grid + the chain of diagonal blocks (costs from the measured kernel constants in DESIGN.md) to
-see where workers would wait.  `python tools/queue_sim.py N [workers]` prints the model's timeline summary.
-
-Used by tests/test_queue_plan.py; also the offline tuning aid for the panel schedule (SGPR_Q_W0/T0/T1/T2/WMAX)."""
+model of the worker grid + the chain of diagonal blocks to see where workers would wait.
+`python tools/queue_sim.py N [workers]` prints the plan's summary.  Used by tests/test_queue_plan.py."""
 import ctypes as C
 import heapq
 import os
@@ -18,217 +16,216 @@ TASK_U, TASK_T = 0, 1
 
 
 def fetch_plan(n, nworkers):
+    """-> (starts, tasks[ntasks, 2] uint32, the planner's own time estimate in us)"""
     from sympgpr_amd import _lib as L
     probe = L.load_probe_library()
-    counts = (C.c_int * 2)()
+    counts = (C.c_int * 3)()
     L.check(probe.sgpr_probe_queue_plan(n, nworkers, None, 0, None, 0, counts), "sgpr_probe_queue_plan")
     nblk, ntasks = counts[0], counts[1]
     starts = (C.c_int * (nblk + 1))()
-    tasks = (C.c_uint * max(ntasks, 1))()
+    tasks = (C.c_uint * max(2 * ntasks, 2))()
     L.check(probe.sgpr_probe_queue_plan(n, nworkers, starts, nblk + 1, tasks, ntasks, counts), "sgpr_probe_queue_plan")
-    t = np.frombuffer(tasks, dtype=np.uint32, count=ntasks).copy()
-    return list(starts), t
+    t = np.frombuffer(tasks, dtype=np.uint32, count=2 * ntasks).reshape(-1, 2).copy()
+    return list(starts), t, float(counts[2])
 
 
 def unpack(t):
-    return int(t >> 30), int((t >> 21) & 511), int((t >> 11) & 1023), int(t & 2047)
+    """-> (type, k, i, j, a, b)"""
+    w0, w1 = int(t[0]), int(t[1])
+    return w0 >> 30, (w0 >> 21) & 511, (w0 >> 11) & 1023, w0 & 2047, w1 >> 16, w1 & 0xFFFF
 
 
-def deps_of(task, starts):
-    """What a task waits for: list of ('ver', i, j, need) / ('tver', i, need) / ('chain', k)."""
-    typ, k, i, j = unpack(task)
-    if typ == TASK_U:
-        return [("ver", i, j, k), ("tver", 2 * i, k + 1), ("tver", 2 * i + 1, k + 1), ("tver", j, k + 1)]
+def chain_tiles(k, starts):
+    """tiles the diagonal strips of panel k wait for"""
     j0, W = starts[k] // TN, (starts[k + 1] - starts[k]) // LEAF
-    return [("ver", i, j0 + c, k) for c in range(W)] + [("chain", k)]
-
-
-def chain_deps(k, starts):
-    """tiles the diagonal strips of panel k wait for (all at version k)"""
-    j0, W = starts[k] // TN, (starts[k + 1] - starts[k]) // LEAF
-    out = []
-    for g in range(W):
-        vi = starts[k] // TM + g // 2
-        out += [(vi, j0 + c) for c in range(g + 1)]
-    return sorted(set(out))
+    return sorted({(starts[k] // TM + g // 2, j0 + c) for g in range(W) for c in range(g + 1)})
 
 
 def check_order(n, starts, tasks):
-    """Every dependency of a task is produced by a task with a smaller ticket (or by the chain, whose own
-    inputs come from smaller tickets than its first consumer).  Returns the number of tasks checked."""
+    """Every input of a task is produced by a task with a smaller ticket, or by a panel kernel whose own inputs
+    are; every tile ends up with all its columns applied, every row strip solved against every panel left of it.
+    The panel kernels are run as late as possible here: a task that needs one gets it only if ITS inputs are there."""
     tm, tn = n // TM, n // TN
-    ver = np.zeros((tm, tn), dtype=np.int64)
-    tver = np.zeros(tn, dtype=np.int64)      # per 128-row strip
-    chain_done = set()
     nblk = len(starts) - 1
-    seen = set()
+    ver = np.zeros((tm, tn), dtype=np.int64)
+    tver = np.zeros(tn, dtype=np.int64)
+    chain_done = set()
 
     def run_chain(k):
-        """the panel kernel of panel k: its diagonal strips, and the rows of the next diagonal block beside them"""
-        for (vi, vj) in chain_deps(k, starts):
-            assert ver[vi, vj] == k, ("chain", k, vi, vj, ver[vi, vj])
+        """panel kernel k: diagonal strips, and the rows of the next diagonal block (all their tiles there first)"""
+        assert k == 0 or (k - 1) in chain_done, ("chain order", k)
+        need = starts[k] // LEAF
+        for (vi, vj) in chain_tiles(k, starts):
+            assert ver[vi, vj] >= need, ("chain", k, vi, vj, ver[vi, vj])
         if k + 1 < nblk:
             j0, W = starts[k] // TN, (starts[k + 1] - starts[k]) // LEAF
             for r in range(starts[k + 1] // LEAF, starts[k + 2] // LEAF):
                 for c in range(W):
-                    assert ver[r // 2, j0 + c] == k, ("band", k, r, c)
-                assert tver[r] == k
-                tver[r] = k + 1
+                    assert ver[r // 2, j0 + c] >= need, ("band", k, r, c)
+                assert tver[r] == need
+                tver[r] = starts[k + 1] // LEAF
         chain_done.add(k)
 
+    def need_chain(k):
+        for q in range(len(chain_done), k + 1):
+            run_chain(q)
+
+    def need_tver(r, v):
+        """row strip r final through column block v: if a panel kernel's band produces it, that kernel must be runnable"""
+        if tver[r] >= v:
+            return
+        k = max(q for q in range(nblk) if starts[q] // LEAF < v)           # the panel whose columns end the range
+        assert k + 1 < nblk and starts[k + 1] // LEAF <= r < starts[k + 2] // LEAF, ("tver", r, v, tver[r])
+        need_chain(k)
+        assert tver[r] >= v, ("tver after panel kernel", r, v, tver[r])
+
     for t in tasks:
-        typ, k, i, j = unpack(t)
-        assert t not in seen, "duplicate task"
-        seen.add(int(t))
-        for d in deps_of(t, starts):
-            if d[0] == "ver":
-                assert ver[d[1], d[2]] == d[3], ("ver", unpack(t), d, ver[d[1], d[2]])
-            elif d[0] == "tver":
-                pass        # checked below, once the panel kernel that may produce it has been given its chance
-            else:
-                if d[1] not in chain_done:
-                    run_chain(d[1])
+        typ, k, i, j, a, b = unpack(t)
         if typ == TASK_U:
-            # inputs solved by the panel kernel itself (rows of the next diagonal block): run it when first asked for
-            if k not in chain_done and all(ver[vi, vj] == k for (vi, vj) in chain_deps(k, starts)):
-                run_chain(k)
-            for d in deps_of(t, starts):
-                if d[0] == "tver":
-                    assert tver[d[1]] >= d[2], ("tver after chain", unpack(t), d, tver[d[1]])
-            assert 256 * i + 255 >= 128 * j and 128 * j >= starts[k + 1] and 256 * i >= starts[k + 1]
-            ver[i, j] = k + 1
+            assert 256 * i + 255 >= 128 * j and a < b
+            assert ver[i, j] == a, ("ver", (i, j, a, b), ver[i, j])
+            for r in (2 * i, 2 * i + 1, j):
+                need_tver(r, b)
+            capj = max(s for s in starts if s <= 128 * j) // LEAF
+            assert b <= capj
+            ver[i, j] = b
         else:
-            assert 256 * i >= starts[k + 2]
-            assert tver[2 * i] == k and tver[2 * i + 1] == k
-            tver[2 * i] = tver[2 * i + 1] = k + 1
-    # completeness: every lower tile right of panel k got panel k's update, every row tile below every panel was solved
-    for k in range(nblk - 1):
-        for r in range(starts[k + 1] // LEAF, tn):
-            assert tver[r] >= k + 1, (k, r, tver[r])
+            need_chain(k)
+            base = starts[k] // LEAF
+            j0, W = starts[k] // TN, (starts[k + 1] - starts[k]) // LEAF
+            assert k + 2 < len(starts) and 256 * i >= starts[k + 2]
+            for c in range(W):
+                assert ver[i, j0 + c] >= base, ("solve", k, i, c)
+            assert tver[2 * i] == base and tver[2 * i + 1] == base, ("solve order", k, i, tver[2 * i])
+            tver[2 * i] = tver[2 * i + 1] = starts[k + 1] // LEAF
+    need_chain(nblk - 1)
     for i in range(tm):
         for j in range(tn):
             if 256 * i + 255 >= 128 * j:
-                kk = max(q for q in range(nblk) if starts[q] <= 128 * j)      # panel that holds column tile j
-                assert ver[i, j] == kk, (i, j, ver[i, j], kk)
+                capj = max(s for s in starts if s <= 128 * j) // LEAF
+                assert ver[i, j] == capj, (i, j, ver[i, j], capj)
+    for k in range(nblk - 1):
+        for r in range(starts[k + 1] // LEAF, tn):
+            assert tver[r] >= starts[k + 1] // LEAF
     return len(tasks)
 
 
 def replay(A, starts, tasks):
-    """Run the list in ticket order on a dense SPD matrix (lower triangle significant); the chain of a panel runs
-    when its first consumer asks for it.  Returns L (lower)."""
+    """Run the list in ticket order on a dense SPD matrix (lower triangle significant); a panel kernel (diagonal
+    block + the rows of the next one) runs as soon as its inputs are complete.  Returns L (lower)."""
     import scipy.linalg
     A = np.array(A, dtype=np.float64, order="F")
-    done = set()
+    n = A.shape[0]
+    tm, tn = n // TM, n // TN
+    nblk = len(starts) - 1
+    ver = np.zeros((tm, tn), dtype=np.int64)
+    done = []
 
-    def chain(k):
-        s0, s1 = starts[k], starts[k + 1]
-        A[s0:s1, s0:s1] = np.linalg.cholesky(np.tril(A[s0:s1, s0:s1]) + np.tril(A[s0:s1, s0:s1], -1).T)
-        if k + 2 < len(starts):
-            r = slice(starts[k + 1], starts[k + 2])
-            A[r, s0:s1] = scipy.linalg.solve_triangular(np.tril(A[s0:s1, s0:s1]), A[r, s0:s1].T, lower=True).T
-        done.add(k)
+    def chains():
+        k = len(done)
+        while k < nblk:
+            need = starts[k] // LEAF
+            tiles = set(chain_tiles(k, starts))
+            if k + 1 < nblk:
+                j0, W = starts[k] // TN, (starts[k + 1] - starts[k]) // LEAF
+                tiles |= {(r // 2, j0 + c) for r in range(starts[k + 1] // LEAF, starts[k + 2] // LEAF) for c in range(W)}
+            if any(ver[t_] < need for t_ in tiles):
+                return
+            s0, s1 = starts[k], starts[k + 1]
+            D = np.tril(A[s0:s1, s0:s1])
+            A[s0:s1, s0:s1] = np.linalg.cholesky(D + np.tril(D, -1).T)
+            if k + 1 < nblk:
+                r = slice(starts[k + 1], starts[k + 2])
+                A[r, s0:s1] = scipy.linalg.solve_triangular(np.tril(A[s0:s1, s0:s1]), A[r, s0:s1].T, lower=True).T
+            done.append(k)
+            k += 1
 
+    chains()
     for t in tasks:
-        typ, k, i, j = unpack(t)
-        s0, s1 = starts[k], starts[k + 1]
+        typ, k, i, j, a, b = unpack(t)
         if typ == TASK_T:
-            if k not in done:
-                chain(k)
-            Lkk = np.tril(A[s0:s1, s0:s1])
+            assert k in done
+            s0, s1 = starts[k], starts[k + 1]
             r = slice(TM * i, TM * i + TM)
-            A[r, s0:s1] = scipy.linalg.solve_triangular(Lkk, A[r, s0:s1].T, lower=True).T
+            A[r, s0:s1] = scipy.linalg.solve_triangular(np.tril(A[s0:s1, s0:s1]), A[r, s0:s1].T, lower=True).T
         else:
-            if k not in done:
-                chain(k)
-            r, c = slice(TM * i, TM * i + TM), slice(TN * j, TN * j + TN)
-            A[r, c] -= A[r, s0:s1] @ A[c, s0:s1].T
-    last = len(starts) - 2
-    if last not in done:
-        chain(last)
+            r, c, kk = slice(TM * i, TM * i + TM), slice(TN * j, TN * j + TN), slice(LEAF * a, LEAF * b)
+            A[r, c] -= A[r, kk] @ A[c, kk].T
+            ver[i, j] = b
+        chains()
+    assert len(done) == nblk
     return np.tril(A)
 
 
-def simulate(n, starts, tasks, nworkers, leaf_us=72.0, kstep_us=3.56, fixed_us=18.0, sync_us=3.0):
-    """Discrete-event model: workers draw tickets in order and hold two (the running one and the next);
-    a task starts when its inputs are there.  The chain of panel k starts when its tiles are there and takes
-    leaf_us per leaf column.  Returns (makespan_us, busy_us, wait_us, chain_spans)."""
+def simulate(n, starts, tasks, nworkers, leaf_us=72.0, pair_us=17.0, kstep_us=3.56, fixed_us=28.0, band0=40.0, band_pair=12.0):
+    """The in-order execution of the list on `nworkers` workers (each takes the next ticket when free and waits for
+    the task's inputs) beside the chain, on the planner's cost model.  Returns (makespan_us, busy_us, wait_us)."""
     tm, tn = n // TM, n // TN
     nblk = len(starts) - 1
-    ver_t = {}      # (i, j, version) -> time that version was published
-    tver_t = {}     # (i, version)
-    for i in range(tm):
-        for j in range(tn):
-            ver_t[(i, j, 0)] = 0.0
-    for r in range(tn):
-        tver_t[(r, 0)] = 0.0
+    ver_t = {(i, j, 0): 0.0 for i in range(tm) for j in range(tn)}
+    tver_t = {(r, 0): 0.0 for r in range(tn)}
     chain_t = {}
-    chain_span = {}
 
-    def chain_ready(k):
+    def chain(k):
         if k in chain_t:
             return chain_t[k]
         W = (starts[k + 1] - starts[k]) // LEAF
-        t0 = 0.0 if k == 0 else chain_t.get(k - 1, 0.0)
-        t_in = max([ver_t.get((vi, vj, k), np.inf) for (vi, vj) in chain_deps(k, starts)] + [t0])
-        chain_span[k] = (t_in, t_in + leaf_us * W)
-        chain_t[k] = t_in + leaf_us * W
+        need = starts[k] // LEAF
+        t0 = 0.0 if k == 0 else chain(k - 1)
+        t_in = max([ver_t.get((vi, vj, need), np.inf) for (vi, vj) in chain_tiles(k, starts)] + [t0])
+        chain_t[k] = t_in + leaf_us * W + pair_us * W * (W - 1) / 2
         if k + 1 < nblk:
-            # the rows of the next diagonal block, solved beside the chain by workgroups of the panel kernel
             j0 = starts[k] // TN
-            work = (W + W * (W - 1) / 2) * 20.0
-            for r in range(starts[k + 1] // LEAF, starts[k + 2] // LEAF):
-                rin = max(ver_t.get((r // 2, j0 + c, k), np.inf) for c in range(W))
-                tver_t[(r, k + 1)] = max(chain_t[k] + 40.0, rin + work)
+            lag = band0 + band_pair * W * (W - 1) / 2
+            rows = range(starts[k + 1] // LEAF, starts[k + 2] // LEAF)
+            rin = max(ver_t.get((r // 2, j0 + c, need), np.inf) for r in rows for c in range(W))
+            for r in rows:
+                tver_t[(r, starts[k + 1] // LEAF)] = max(chain_t[k], rin) + lag
         return chain_t[k]
 
-    def cost(task):
-        typ, k, i, j = unpack(task)
-        w = starts[k + 1] - starts[k]
-        if typ == TASK_U:
-            return kstep_us * w / 16 + fixed_us
-        W = w // LEAF
-        ksteps = sum(8 * c for c in range(1, W)) + 8 * W
-        return kstep_us * ksteps + (2 * W - 1) * 12.0
+    def tver_time(r, v):
+        if (r, v) not in tver_t:
+            chain(max(q for q in range(nblk) if starts[q] // LEAF < v))
+        return tver_t.get((r, v), np.inf)
 
     free = [(0.0, wk) for wk in range(nworkers)]
     heapq.heapify(free)
-    busy = wait = 0.0
-    end = 0.0
+    busy = wait = end = 0.0
     for t in tasks:
         tw, wk = heapq.heappop(free)
-        typ, k, i, j = unpack(t)
-        ready = 0.0
-        for d in deps_of(t, starts):
-            if d[0] == "ver":
-                ready = max(ready, ver_t.get((d[1], d[2], d[3]), np.inf))
-            elif d[0] == "tver":
-                if (d[1], d[2]) not in tver_t:
-                    chain_ready(k)
-                ready = max(ready, tver_t.get((d[1], d[2]), np.inf))
-            else:
-                ready = max(ready, chain_ready(d[1]))
-        assert np.isfinite(ready), unpack(t)
-        start = max(tw, ready) + sync_us
-        c = cost(t)
-        fin = start + c
-        wait += max(0.0, ready - tw)
-        busy += c
+        typ, k, i, j, a, b = unpack(t)
         if typ == TASK_U:
-            ver_t[(i, j, k + 1)] = fin
+            ready = max(ver_t.get((i, j, a), np.inf), tver_time(2 * i, b), tver_time(2 * i + 1, b), tver_time(j, b))
+            c_us = kstep_us * 8 * (b - a) + fixed_us
         else:
-            tver_t[(2 * i, k + 1)] = tver_t[(2 * i + 1, k + 1)] = fin
+            base = starts[k] // LEAF
+            j0, W = starts[k] // TN, (starts[k + 1] - starts[k]) // LEAF
+            ready = max([ver_t.get((i, j0 + c, base), np.inf) for c in range(W)] + [chain(k)])
+            c_us = kstep_us * (sum(8 * c for c in range(1, W)) + 8 * W) + (2 * W - 1) * fixed_us * 0.5
+        assert np.isfinite(ready), unpack(t)
+        start = max(tw, ready)
+        fin = start + c_us
+        wait += max(0.0, ready - tw)
+        busy += c_us
+        if typ == TASK_U:
+            ver_t[(i, j, b)] = fin
+        else:
+            tver_t[(2 * i, starts[k + 1] // LEAF)] = tver_t[(2 * i + 1, starts[k + 1] // LEAF)] = fin
         end = max(end, fin)
         heapq.heappush(free, (fin, wk))
-    end = max(end, chain_ready(nblk - 1))
-    return end, busy, wait, chain_span
+    end = max(end, chain(nblk - 1))
+    return end, busy, wait
 
 
 if __name__ == "__main__":
     n = int(sys.argv[1])
     nw = int(sys.argv[2]) if len(sys.argv) > 2 else 248
-    starts, tasks = fetch_plan(n, nw)
-    print("n=%d panels=%d widths=%s tasks=%d" % (n, len(starts) - 1, np.diff(starts).tolist(), len(tasks)))
-    check_order(n, starts, tasks)
-    end, busy, wait, spans = simulate(n, starts, tasks, nw)
-    print("model: %.2f ms  (= %.1f TFLOP/s)  workers busy %.1f %%  waiting %.1f %%" % (
-        end / 1e3, n**3 / 3 / end / 1e6, 100 * busy / (end * nw), 100 * wait / (end * nw)))
+    starts, tasks, model_us = fetch_plan(n, nw)
+    ks = np.array([(unpack(t)[5] - unpack(t)[4]) for t in tasks if unpack(t)[0] == TASK_U])
+    print("n=%d panels=%d (width %d) tasks=%d  mean k of an update %.0f  planner estimate %.2f ms (%.1f TFLOP/s)" % (
+        n, len(starts) - 1, starts[1], len(tasks), 128 * ks.mean(), model_us / 1e3, n**3 / 3 / max(model_us, 1) / 1e6))
+    print("k histogram (x128):", {int(k): int(c) for k, c in enumerate(np.bincount(ks)) if c})
+    if n <= 8192:
+        check_order(n, starts, tasks)
+    end, busy, wait = simulate(n, starts, tasks, nw)
+    print("in-order replay on the model: %.2f ms  workers busy %.1f %%  waiting %.1f %%" % (end / 1e3, 100 * busy / (end * nw), 100 * wait / (end * nw)))

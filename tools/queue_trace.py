@@ -16,7 +16,7 @@ n = 2 * N
 probe = L.load_probe_library()
 q, P, z, hyp, s2 = synth(N)
 cap = 1 << 19
-nwords = 4 * cap + 2048 + 65536
+nwords = 8 * cap + 2048 + 65536
 buf = (C.c_ulonglong * nwords)()
 failed = None
 with SympFit("A", q, P, z, hyp, s2, lower_only=False) as f:
@@ -34,9 +34,9 @@ with SympFit("A", q, P, z, hyp, s2, lower_only=False) as f:
         probe.sgpr_probe_queue_postmortem(1)
     nw = probe.sgpr_probe_queue_trace_end(buf, cap)
 allw = np.frombuffer(buf, dtype=np.uint64, count=nwords)
-tr = allw[:4 * cap].reshape(-1, 4)
-wc = allw[4 * cap:4 * cap + 2048].reshape(-1, 2)
-pc = allw[4 * cap + 2048:].reshape(512, 32, 4)
+tr = allw[:8 * cap].reshape(-1, 8)
+wc = allw[8 * cap:8 * cap + 2048].reshape(-1, 2)
+pc = allw[8 * cap + 2048:].reshape(512, 32, 4)
 tr = tr[tr[:, 2] != 0]
 print("n=%d factor %s ms (traced run %.2f ms), %d traced tasks%s" % (n, ("%.2f" % min(ts)) if ts else "-", traced_ms, len(tr),
                                                                      "  FAILED: %s" % failed if failed else ""))
@@ -60,24 +60,29 @@ for k in range(512):
     st = (x[:, 1].astype(np.int64) - int(t0)) / 100.0
     en = (x[:, 2].astype(np.int64) - int(t0)) / 100.0
     order = np.argsort(x[:, 3])
-    if k < 6 or failed:
-        print("  panel %2d: %2d workgroups, start %8.0f..%8.0f us, end %8.0f..%8.0f us, on worker CUs: %d; strips/start/end: %s" % (
-            k, m.sum(), st.min(), st.max(), en[en > -1e9].min() if (x[:, 2] != 0).any() else -1, en.max(), shared,
-            " ".join("%d:%.0f-%.0f" % (int(x[o, 3]), st[o], en[o] if x[o, 2] else -1) for o in order)))
+    if k % 4 == 0 or failed:
+        nd = int((x[:, 3] < 4).sum())
+        print("  panel %2d: start %8.0f us; diagonal strips end %s; rows of the next block end %8.0f; on worker CUs: %d" % (
+            k, st.min(), " ".join("%.0f" % en[o] for o in order[:nd]), en[order[nd:]].max() if len(order) > nd else -1, shared))
 if len(tr):
     drawn = (tr[:, 0].astype(np.int64) - int(t0)) / 100.0
     ready = (tr[:, 1].astype(np.int64) - int(t0)) / 100.0
     done = (tr[:, 2].astype(np.int64) - int(t0)) / 100.0
-    task = (tr[:, 3] & 0xFFFFFFFF).astype(np.uint32)
-    typ = (task >> 30).astype(int); k = ((task >> 21) & 511).astype(int)
-    print("worker kernel span %.2f ms; sum busy (ready->done) %.1f ms, sum wait (drawn->ready) %.1f ms" % (
-        done.max() / 1e3, (done - ready).sum() / 1e3, (ready - drawn).sum() / 1e3))
-    for kk in sorted(set(k)):
-        for ty, name in ((1, "T"), (0, "U")):
-            m = (k == kk) & (typ == ty)
-            if m.any():
-                print("  panel %2d %s: n=%5d  drawn %8.0f..%8.0f us  wait mean %6.1f max %7.1f  run mean %6.1f  (min %6.1f max %6.1f)" % (
-                    kk, name, m.sum(), drawn[m].min(), drawn[m].max(), (ready - drawn)[m].mean(), (ready - drawn)[m].max(),
-                    (done - ready)[m].mean(), (done - ready)[m].min(), (done - ready)[m].max()))
+    w0 = (tr[:, 3] & 0xFFFFFFFF).astype(np.uint32); w1 = ((tr[:, 3] >> 32) & 0x0FFFFFFF).astype(np.uint32)
+    typ = (w0 >> 30).astype(int); kk = (w1 & 0xFFFF).astype(int) - (w1 >> 16).astype(int)
+    run, wait = done - ready, ready - drawn
+    print("worker kernel span %.2f ms; sum busy (start->done) %.1f ms, sum idle (free->start) %.1f ms" % (
+        done.max() / 1e3, run.sum() / 1e3, wait.sum() / 1e3))
+    for k_ in sorted(set(kk[typ == 0])):
+        m = (typ == 0) & (kk == k_)
+        print("  update k=%4d: n=%5d  run mean %6.1f (min %6.1f)  = k-steps + %5.1f   idle before: mean %6.1f" % (
+            128 * k_, m.sum(), run[m].mean(), run[m].min(), run[m].mean() - 3.56 * 8 * k_, wait[m].mean()))
+    for c in sorted(set(w1[typ == 1].tolist())):
+        m = (typ == 1) & (w1 == c)
+        print("  solve column %d: n=%5d  run mean %6.1f (min %6.1f)  idle before: mean %6.1f" % (c, m.sum(), run[m].mean(), run[m].min(), wait[m].mean()))
+    edges = np.arange(0, done.max() + 500, 1000.0)
+    nwk = max(len(wc), 1)
+    print("busy fraction per ms:", " ".join("%.2f" % (np.clip(np.minimum(done, e1) - np.maximum(ready, e0), 0, None).sum() / (nwk * (e1 - e0)))
+                                            for e0, e1 in zip(edges[:-1], edges[1:])))
 if len(args) > 1:
     np.savez_compressed(args[1], tr=tr, wc=wc, pc=pc[:64])
