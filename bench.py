@@ -103,7 +103,8 @@ def kernel_code_hash():
     from a profile taken with exactly these sources)."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("gemm_f64.hip", "gemm_tile.h", "chol.hip", "gram.hip", "gram_nd.hip"):
+    for f in ("common.h", "devmath.h", "pair_eval.h", os.path.join("generated", "pair_generated.h"), "leaf.h", "gemm_f64.hip",
+              "gemm_tile.h", "chol.hip", "cholq.hip", "cholq.h", "trsv.hip", "gram.hip", "gram_nd.hip"):
         with open(os.path.join(ROOT, "sympgpr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -194,10 +195,13 @@ def main():
     L.check(lib.sgpr_set_device(local_rank))
     if world > 1:
         import torch.distributed as dist
+        from datetime import timedelta
+        # a collective that does not complete within 5 minutes ends the rank with a non-zero exit code (the NCCL / RCCL
+        # watchdog aborts the process; nothing here re-launches or re-execs a rank that has touched the GPU)
         if one_card:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=timedelta(minutes=5))
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(minutes=5))
 
     def barrier():
         if world > 1:
@@ -209,10 +213,18 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             import torch.distributed as dist
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            from datetime import timedelta
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank),
+                                    timeout=timedelta(minutes=5))
         from sympgpr_amd.dist_bench import run_distributed
-        return run_distributed(args, rank, local_rank, world, synth, METRIC,
-                               {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS}, synth_pairs, cpu_baseline)
+        try:
+            return run_distributed(args, rank, local_rank, world, synth, METRIC,
+                                   {"mfma": MFMA_F64_PEAK_TF, "hbm": HBM_PEAK_GBS}, synth_pairs, cpu_baseline)
+        except Exception as e:           # a collective timeout, a factor error on some rank, ...: say where, exit non-zero
+            from sympgpr_amd import dist_bench
+            sys.stderr.write("bench.py rank %d/%d FAILED in stage '%s': %s: %s\n" % (rank, world, dist_bench.STAGE[0], type(e).__name__, e))
+            sys.stderr.flush()
+            os._exit(3)
 
     n_pts = args.n_pts
     d = args.d
@@ -299,20 +311,23 @@ def main():
     alone_n, alone_flop, alone_ms = prof[0], prof[1], prof[2]
     ov_n, ov_flop, ov_ms = prof[8], prof[9], prof[10]
     if alone_n + ov_n > 0:
-        # `achieved` = launches that had the device to themselves (sum of their durations <= wall time);
-        # the launches of the look-ahead driver run two streams at once and are reported beside it
-        base_n, base_flop, base_ms = (alone_n, alone_flop, alone_ms) if alone_n > 0 else (ov_n, ov_flop, ov_ms)
-        ach = base_flop / (base_ms * 1e-3) / 1e12
+        # `achieved` = ALL launches of the kernel: sum of their algorithmic flop / sum of their durations -- what the
+        # rocprofv3 kernel stats of the same command reproduce.  The launches that had the device to themselves
+        # (the look-ahead driver's run two streams at once, so theirs overlap other work) are quoted beside it.
+        all_n, all_flop, all_ms = alone_n + ov_n, alone_flop + ov_flop, alone_ms + ov_ms
+        ach = all_flop / (all_ms * 1e-3) / 1e12
+        ach_alone = alone_flop / (alone_ms * 1e-3) / 1e12 if alone_ms > 0 else None
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (fp64 MFMA trailing update)",
                            "achieved": ach, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
                            "frac": ach / MFMA_F64_PEAK_TF, "traffic": traffic.get("gemm"),
                            "traffic_source": traffic_source,
-                           "timing": "one untimed extra step, HIP-event pair per launch on the launch stream",
-                           "launches": int(base_n), "flop_per_launch": base_flop / base_n,
-                           "avg_launch_ms": base_ms / base_n,
+                           "timing": "one untimed extra step, HIP-event pair per launch on the launch stream; all launches",
+                           "launches": int(all_n), "flop_per_launch": all_flop / all_n,
+                           "avg_launch_ms": all_ms / all_n,
+                           "achieved_alone": ach_alone,
+                           "frac_alone": ach_alone / MFMA_F64_PEAK_TF if ach_alone else None,
                            "launches_alone": int(alone_n), "launches_overlapped": int(ov_n),
                            "achieved_overlapped": (ov_flop / (ov_ms * 1e-3) / 1e12) if ov_ms > 0 else None,
-                           "achieved_all_launches": (alone_flop + ov_flop) / ((alone_ms + ov_ms) * 1e-3) / 1e12,
                            "sum_launch_ms_alone": alone_ms, "sum_launch_ms_overlapped": ov_ms,
                            "launches_untimed": int(prof[11]),
                            "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 1
+#define SGPR_ABI_VERSION 2   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library */
 
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
@@ -214,8 +214,23 @@ int sgpr_gram_reg_dev(int family, int mi, int mj, const double *xb, const double
 int sgpr_gram_nd_dev(int family, int d, int mi, int mj, const double *Xb, size_t ldxb,
                      const double *Xa, size_t ldxa, const double *hyp, int nhyp, double *K, size_t ld,
                      size_t rstride, size_t cstride, long diag_off, double noise, void *stream);
+/* The same pairs, but only the blocks (a, b) with roff[a] >= 0 and coff[b] >= 0 (2d entries each, host arrays), block
+ * (a, b) at K + roff[a] + coff[b] * ld: for a block-cyclic rank whose coordinate blocks hold DIFFERENT points (N / nb not a
+ * multiple of the process grid), one call per pair of distinct point selections. */
+int sgpr_gram_nd_sel_dev(int family, int d, int mi, int mj, const double *Xb, size_t ldxb,
+                         const double *Xa, size_t ldxa, const double *hyp, int nhyp, double *K, size_t ld,
+                         const long *roff, const long *coff, void *stream);
 /* workspace (bytes) sgpr_potrf_dev / sgpr_trsm_rlt_dev need for order n */
 size_t sgpr_potrf_workspace(int n);
+/* The workspace BEGINS with the inverses of the 128 x 128 diagonal leaves of L (ceil(n / 128) blocks of 128 x 128
+ * doubles): these bytes, with L itself, are all sgpr_trsm_rlt_dev / sgpr_trsv_dev read of what sgpr_potrf_dev leaves
+ * there -- what a distributed driver has to send along with a diagonal block.  The rest is scratch. */
+size_t sgpr_potrf_inverses_bytes(int n);
+/* sgpr_potrf_dev keeps, per device, one high-priority side stream shared by all callers (every panel kernel of the device
+ * runs on it, one at a time, whatever number of handles / host threads factor at once) and, with SGPR_POTRF_Q=1, a pair
+ * of CU-masked streams.  They are created on first use and live until this call drains and destroys them (they come
+ * back on demand).  Call it with no factorisation being enqueued on `device`; never needed for correctness. */
+int sgpr_release_device_streams(int device);
 /* lower Cholesky in place; only the lower triangle of A is read or written.
  * dinfo: device int, 0 or the 1-based failing minor. */
 int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo,
@@ -236,9 +251,15 @@ int sgpr_gemm_nt_dev(int m, int n, int k, double alpha, const double *A, size_t 
 int sgpr_gemm_nt_bc_dev(int m, int n, int k, double alpha, const double *A, size_t lda,
                         const double *B, size_t ldb, double beta, double *C, size_t ldc, int blk,
                         int pr, int pi, int pc, int pj, void *stream);
-/* b (n) := L^-1 b (trans = 0) or L^-T b (trans != 0); `work` as left by sgpr_potrf_dev on L */
-int sgpr_trsv_dev(int n, const double *L, size_t ldl, const void *work, double *b, int trans,
+/* b (n) := L^-1 b (trans = 0) or L^-T b (trans != 0); `work` as left by sgpr_potrf_dev on L.
+ * The one-launch strip solves keep their tickets, progress counters and published segments IN the workspace: ONE solve
+ * per workspace at a time (a second stream solving against the same factor needs its own copy of `work`). */
+int sgpr_trsv_dev(int n, const double *L, size_t ldl, void *work, double *b, int trans,
                   void *stream);
+/* Waits for `stream`, then: 0, or SGPR_E_HIP when a strip solve on this workspace gave up on a hand-off between two
+ * workgroups (a bounded wait ran out: a device problem, never a property of the matrix).  Call it after the last
+ * sgpr_trsv_dev / sgpr_potrs_vec_dev of a solve before trusting b. */
+int sgpr_solve_status_dev(int n, const double *L, size_t ldl, const void *work, void *stream);
 /* y -= A x (trans = 0: A m x k, x k, y m) or y -= A^T x (trans != 0: x m, y k) */
 int sgpr_gemv_sub_dev(int trans, int m, int k, const double *A, size_t lda, const double *x,
                       double *y, void *stream);
@@ -277,7 +298,7 @@ int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hy
                        const double *ytrainp, const double *alphap, const double *Q0,
                        const double *P0, double *qmap, double *pmap, double *pdiff);
 /* alpha-solve on device with the factor and its leaf inverses: b (n) := L^-T L^-1 b */
-int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b,
+int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, void *work, double *b,
                        void *stream);
 
 /* Per-launch HIP-event timing of the MFMA GEMM kernel between begin and end (measurement

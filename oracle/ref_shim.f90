@@ -6,6 +6,7 @@
 module sympgpr_ref_shim
     use iso_c_binding
     use sympgpr, only: build_K, buildKreg, guessP, calcq, calcP, applymap_tok
+    use fieldlines, only: fl_init => init, fl_ath => Ath, fl_timestep => timestep, fl_compute_r => compute_r
     implicit none
 contains
 
@@ -66,5 +67,35 @@ subroutine ref_applymap_tok(nm, ntest, hyp, hypp, Q0map, P0map, np, xtrainp, ytr
     call applymap_tok(nm_, ntest_, hyp, hypp, Q0map, P0map, xtrainp, ytrainp, ztrainp, Kyinvp, &
         xtrain, ytrain, ztrain, Kyinv, qmap, pmap)
 end subroutine
+
+! module fieldlines (python/05_tokamak/Split_SympGPR/fieldlines.f90, the same file as SympGPR/fieldlines.f90): what
+! calc_fieldlines.py:28-40 and Split_SympGPR/func.py:211 call through f2py
+subroutine ref_fl_init(nph, am, an, aeps, aphase, arlast) bind(C, name="ref_fl_init")
+    integer(c_int), value :: nph, am, an
+    real(c_double), value :: aeps, aphase, arlast
+    integer :: nph_, am_, an_
+    real(c_double) :: aeps_, aphase_, arlast_
+    nph_ = nph; am_ = am; an_ = an
+    aeps_ = aeps; aphase_ = aphase; arlast_ = arlast
+    call fl_init(nph_, am_, an_, aeps_, aphase_, arlast_)
+end subroutine
+
+function ref_fl_ath(r, th, ph) bind(C, name="ref_fl_ath") result(v)
+    real(c_double), value :: r, th, ph
+    real(c_double) :: v
+    v = fl_ath(r, th, ph)
+end function
+
+subroutine ref_fl_timestep(z) bind(C, name="ref_fl_timestep")
+    real(c_double), intent(inout) :: z(3)
+    call fl_timestep(z)
+end subroutine
+
+function ref_compute_r(z, rstart) bind(C, name="ref_compute_r") result(r)
+    real(c_double), intent(in) :: z(3)
+    real(c_double), value :: rstart
+    real(c_double) :: r
+    r = fl_compute_r(z, rstart)
+end function
 
 end module sympgpr_ref_shim

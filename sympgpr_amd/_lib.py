@@ -13,6 +13,7 @@ FIT_LOWER_ONLY, FIT_REG, FIT_BLOCK_QQ, FIT_BLOCK_PP = 1, 4, 8, 16
 MAP_WRAP_Q, MAP_WRAP_P, MAP_EXPLICIT = 1, 2, 4
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
+ABI_VERSION = 2      # include/sympgpr_hip.h: SGPR_ABI_VERSION
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -77,7 +78,11 @@ SIGNATURES = {
                                    _vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_long, C.c_double, _vp]),
     "sgpr_gram_reg_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, C.c_int, _vp, C.c_size_t,
                                     C.c_long, C.c_double, _vp]),
+    "sgpr_gram_nd_sel_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _dp, C.c_int,
+                                       _vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_long), _vp]),
     "sgpr_potrf_workspace": (C.c_size_t, [C.c_int]),
+    "sgpr_potrf_inverses_bytes": (C.c_size_t, [C.c_int]),
+    "sgpr_release_device_streams": (C.c_int, [C.c_int]),
     "sgpr_potrf_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_trsm_rlt_dev": (C.c_int, [C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_gemm_nt_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t,
@@ -97,6 +102,7 @@ SIGNATURES = {
     "sgpr_applymap_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _dp, _dp, _dp,
                                      C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "sgpr_potrs_vec_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "sgpr_solve_status_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_fit_batch_max_order": (C.c_int, []),
     "sgpr_fit_batch": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_uint, _dp, _dp,
                                  C.POINTER(C.c_int)]),
@@ -152,8 +158,9 @@ def load_library():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.sgpr_abi_version() != 1:
-        raise SympGPRError("ABI version mismatch")
+    if lib.sgpr_abi_version() != ABI_VERSION:
+        raise SympGPRError("ABI version mismatch: %s is version %d, this package binds version %d -- rebuild it "
+                           "(make -C sympgpr_amd/csrc)" % (path, lib.sgpr_abi_version(), ABI_VERSION))
     _LIB = lib
     return lib
 

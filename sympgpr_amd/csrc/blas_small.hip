@@ -105,64 +105,66 @@ __global__ void transpose_kernel(int m, int n, const double *A, size_t lda, doub
     }
 }
 
-// y(m) -= A(m x k) x(k).  Workgroup = 512 rows (2 per thread) x a chunk of KC columns; the
-// column chunks combine with fp64 atomics (HBM-bound: A is read exactly once).
+// y(m) -= A(m x k) x(k).  Workgroup = 512 rows (2 per thread), ALL k columns in chunks of KC staged through LDS: every
+// element of y has one owner and one fixed order of summation, so the result is bitwise reproducible (round 2 split the
+// columns over workgroups and combined them with fp64 atomics: alpha of the small-order fallback then differed in the last
+// bits from run to run, which the reference's LAPACK path never does).  HBM-bound: A is read exactly once.
 constexpr int GV_T = 256, GV_ROWS = 2 * GV_T, GV_KC = 128;
 __global__ __launch_bounds__(GV_T) void gemv_n_kernel(int m, int k, const double *A, size_t lda,
                                                       const double *x, double *y)
 {
     __shared__ double sx[GV_KC];
-    const int k0 = blockIdx.y * GV_KC;
-    const int kn = min(GV_KC, k - k0);
-    if (threadIdx.x < kn) sx[threadIdx.x] = x[k0 + threadIdx.x];
-    __syncthreads();
     const int i = blockIdx.x * GV_ROWS + 2 * threadIdx.x;
-    if (i >= m) return;
-    const double *a = A + (size_t)i + (size_t)k0 * lda;
-    double s0 = 0.0, s1 = 0.0;
     const bool vec = (i + 1 < m) && ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
-    if (vec) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k0 = 0; k0 < k; k0 += GV_KC) {
+        const int kn = min(GV_KC, k - k0);
+        __syncthreads();
+        if (threadIdx.x < kn) sx[threadIdx.x] = x[k0 + threadIdx.x];
+        __syncthreads();
+        if (i >= m) continue;
+        const double *a = A + (size_t)i + (size_t)k0 * lda;
+        if (vec) {
 #pragma unroll 4
-        for (int c = 0; c < kn; ++c) {
-            const double2_t v = *reinterpret_cast<const double2_t *>(a + (size_t)c * lda);
-            s0 = __builtin_fma(v.x, sx[c], s0);
-            s1 = __builtin_fma(v.y, sx[c], s1);
-        }
-    } else {
-        for (int c = 0; c < kn; ++c) {
-            s0 = __builtin_fma(a[(size_t)c * lda], sx[c], s0);
-            if (i + 1 < m) s1 = __builtin_fma(a[(size_t)c * lda + 1], sx[c], s1);
+            for (int c = 0; c < kn; ++c) {
+                const double2_t v = *reinterpret_cast<const double2_t *>(a + (size_t)c * lda);
+                s0 = __builtin_fma(v.x, sx[c], s0);
+                s1 = __builtin_fma(v.y, sx[c], s1);
+            }
+        } else {
+            for (int c = 0; c < kn; ++c) {
+                s0 = __builtin_fma(a[(size_t)c * lda], sx[c], s0);
+                if (i + 1 < m) s1 = __builtin_fma(a[(size_t)c * lda + 1], sx[c], s1);
+            }
         }
     }
-    if (gridDim.y == 1) {
-        y[i] -= s0;
-        if (i + 1 < m) y[i + 1] -= s1;
-    } else {
-        atomicAdd(&y[i], -s0);
-        if (i + 1 < m) atomicAdd(&y[i + 1], -s1);
-    }
+    if (i >= m) return;
+    y[i] -= s0;
+    if (i + 1 < m) y[i + 1] -= s1;
 }
 
-// y(k) -= A(m x k)^T x(m).  One wave per column over a chunk of rows; wave-reduce; atomics
-// across row chunks.
-constexpr int GT_ROWS = 4096;
+// y(k) -= A(m x k)^T x(m).  One wave per column over ALL rows, then a wave reduction in a fixed order: no atomics,
+// bitwise reproducible.
 __global__ __launch_bounds__(256) void gemv_t_kernel(int m, int k, const double *A, size_t lda,
                                                      const double *x, double *y)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wave;
-    const int r0 = blockIdx.y * GT_ROWS;
-    const int r1 = min(m, r0 + GT_ROWS);
-    double s = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (c < k) {
         const double *a = A + (size_t)c * lda;
-        for (int i = r0 + lane; i < r1; i += 64) s = __builtin_fma(a[i], x[i], s);
+        int i = lane;
+        for (; i + 192 < m; i += 256) {                      // four independent chains per lane
+            s0 = __builtin_fma(a[i], x[i], s0);
+            s1 = __builtin_fma(a[i + 64], x[i + 64], s1);
+            s2 = __builtin_fma(a[i + 128], x[i + 128], s2);
+            s3 = __builtin_fma(a[i + 192], x[i + 192], s3);
+        }
+        for (; i < m; i += 64) s0 = __builtin_fma(a[i], x[i], s0);
     }
+    double s = (s0 + s1) + (s2 + s3);
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0 && c < k) {
-        if (gridDim.y == 1) y[c] -= s;
-        else atomicAdd(&y[c], -s);
-    }
+    if (lane == 0 && c < k) y[c] -= s;
 }
 
 }  // namespace
@@ -237,8 +239,7 @@ int transpose(int m, int n, const double *A, size_t lda, double *B, size_t ldb, 
 int gemv_n_sub(int m, int k, const double *A, size_t lda, const double *x, double *y, hipStream_t st)
 {
     if (m <= 0 || k <= 0) return 0;
-    hipLaunchKernelGGL(gemv_n_kernel, dim3((m + GV_ROWS - 1) / GV_ROWS, (k + GV_KC - 1) / GV_KC),
-                       dim3(GV_T), 0, st, m, k, A, lda, x, y);
+    hipLaunchKernelGGL(gemv_n_kernel, dim3((m + GV_ROWS - 1) / GV_ROWS), dim3(GV_T), 0, st, m, k, A, lda, x, y);
     SGPR_CHECK_LAUNCH();
     return 0;
 }
@@ -246,8 +247,7 @@ int gemv_n_sub(int m, int k, const double *A, size_t lda, const double *x, doubl
 int gemv_t_sub(int m, int k, const double *A, size_t lda, const double *x, double *y, hipStream_t st)
 {
     if (m <= 0 || k <= 0) return 0;
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((k + 3) / 4, (m + GT_ROWS - 1) / GT_ROWS), dim3(256), 0, st,
-                       m, k, A, lda, x, y);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((k + 3) / 4), dim3(256), 0, st, m, k, A, lda, x, y);
     SGPR_CHECK_LAUNCH();
     return 0;
 }

@@ -309,8 +309,10 @@ int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, i
         if ((rc = potrs_mat(n, dL.as<double>(), ld, dW.p, dB.as<double>(), ld, nrhs, dS.as<double>(), st))) return rc;
         SGPR_HIP(hipStreamSynchronize(st));
     } else
-    for (int r = 0; r < nrhs; ++r)
+    for (int r = 0; r < nrhs; ++r) {
         if ((rc = potrs_vec(n, dL.as<double>(), ld, dW.p, dB.as<double>() + (size_t)r * ld, st))) return rc;
+        if ((rc = solve_status(n, dL.as<double>(), ld, dW.p, st))) return rc;     // the next solve reuses the hand-off words
+    }
     SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, ld * sizeof(double), ld * sizeof(double), nrhs,
                               hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipStreamSynchronize(st));
@@ -628,8 +630,10 @@ int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs)
         if ((rc = potrs_mat(f->n, f->dA, n, f->work, dB.as<double>(), n, nrhs, dS.as<double>(), f->st))) return rc;
         SGPR_HIP(hipStreamSynchronize(f->st));
     } else
-    for (int r = 0; r < nrhs; ++r)
+    for (int r = 0; r < nrhs; ++r) {
         if ((rc = potrs_vec(f->n, f->dA, n, f->work, dB.as<double>() + (size_t)r * n, f->st))) return rc;
+        if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;       // the next solve reuses the hand-off words
+    }
     SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, n * sizeof(double), n * sizeof(double), nrhs,
                               hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
@@ -868,7 +872,24 @@ int sgpr_gram_nd_dev(int family, int d, int mi, int mj, const double *Xb, size_t
                    std::fabs(noise), static_cast<hipStream_t>(stream));
 }
 
+int sgpr_gram_nd_sel_dev(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa,
+                         size_t ldxa, const double *hyp, int nhyp, double *K, size_t ld, const long *roff,
+                         const long *coff, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return gram_nd_sel(family, d, mi, mj, Xb, ldxb, Xa, ldxa, hyp, nhyp, K, ld, roff, coff, static_cast<hipStream_t>(stream));
+}
+
 size_t sgpr_potrf_workspace(int n) { return potrf_workspace(n); }
+size_t sgpr_potrf_inverses_bytes(int n) { return n <= 0 ? 0 : (size_t)((n + LEAF - 1) / LEAF) * LEAF * LEAF * sizeof(double); }
+
+int sgpr_release_device_streams(int device)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return release_device_streams(device);
+}
 
 int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, void *stream)
 {
@@ -905,7 +926,7 @@ int sgpr_gemm_nt_bc_dev(int m, int n, int k, double alpha, const double *A, size
     return gemm_nt_bc(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, 1, bc, static_cast<hipStream_t>(stream));
 }
 
-int sgpr_trsv_dev(int n, const double *L, size_t ldl, const void *work, double *b, int trans, void *stream)
+int sgpr_trsv_dev(int n, const double *L, size_t ldl, void *work, double *b, int trans, void *stream)
 {
     int rc = need_device();
     if (rc) return rc;
@@ -1006,11 +1027,18 @@ int sgpr_profile_end(double *out12)
 
 int sgpr_profile_launches(double *buf, int max_records) { return gemm_profile_launches(buf, max_records); }
 
-int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, const void *work, double *b, void *stream)
+int sgpr_potrs_vec_dev(int n, const double *L, size_t ldl, void *work, double *b, void *stream)
 {
     int rc = need_device();
     if (rc) return rc;
     return potrs_vec(n, L, ldl, work, b, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_solve_status_dev(int n, const double *L, size_t ldl, const void *work, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return solve_status(n, L, ldl, work, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

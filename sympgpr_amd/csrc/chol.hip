@@ -973,10 +973,20 @@ struct StreamJoin {
     }
 };
 
-// the high-priority side stream of the device that owns the caller's stream (created on first use, one per device)
+// The high-priority side stream of the device that owns the caller's stream (created on first use, ONE per device,
+// shared by every handle and every host thread; release_device() gives it back).
+//
+// Forward progress with several handles factoring at once: every panel_kernel of a device is launched on this one
+// in-order stream, so at most one panel kernel -- one set of spinning strips -- is resident per device at any time,
+// whatever number of handles / threads are factoring.  The workgroups it waits for are its own (dispatched in block
+// order, each as soon as ONE CU drains); everything else on the device is an MFMA / Gram / solve launch whose
+// workgroups end by themselves.  tests/test_gpu_threads.py runs three handles at n = 16384 against this.
+hipStream_t g_side[64] = {};
+std::mutex g_side_mu;                                      // two fit handles may factor for the first time at once
+
 int side_stream(hipStream_t caller, hipStream_t *out, int *dev_out)
 {
-    static hipStream_t side[64] = {};
+    hipStream_t *const side = g_side;
     int dev = -1;
     if (caller) {
         SGPR_HIP(hipStreamGetDevice(caller, &dev));        // the device that owns the caller's stream
@@ -984,8 +994,7 @@ int side_stream(hipStream_t caller, hipStream_t *out, int *dev_out)
         SGPR_HIP(hipGetDevice(&dev));                      // the null stream belongs to the current device
     }
     if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
-    static std::mutex mu;                                  // two fit handles may factor for the first time at once
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(g_side_mu);
     if (!side[dev]) {
         int cur = -1, lo = 0, hi = 0;
         SGPR_HIP(hipGetDevice(&cur));
@@ -1109,6 +1118,42 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         SGPR_HIP(hipStreamSynchronize(su));
         cholq::postmortem(false);
     }
+    return 0;
+}
+
+int release_streams(int dev)
+{
+    // drain and destroy the streams this library created on `dev` (side stream, the queue driver's masked pair and its
+    // event); the next factorisation creates them again.  The caller guarantees no factorisation is being enqueued.
+    int cur = -1;
+    SGPR_HIP(hipGetDevice(&cur));
+    if (cur != dev) SGPR_HIP(hipSetDevice(dev));
+    hipError_t first = hipSuccess;
+    auto drop = [&](hipStream_t &s) {
+        if (!s) return;
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipStreamDestroy(s);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+        s = nullptr;
+    };
+    {
+        std::lock_guard<std::mutex> lock(g_side_mu);
+        drop(g_side[dev]);
+    }
+    {
+        QueueDevice &qd = g_qdev[dev];
+        std::lock_guard<std::mutex> lock(qd.mu);
+        for (int r = 0; r < 4; ++r) { drop(qd.workers[r]); drop(qd.panels[r]); }
+        if (qd.done) {
+            const hipError_t e = hipEventDestroy(qd.done);
+            if (e != hipSuccess && first == hipSuccess) first = e;
+            qd.done = nullptr;
+        }
+        qd.ncu = 0;
+        qd.failed = false;
+    }
+    if (cur != dev) (void)hipSetDevice(cur);
+    SGPR_HIP(first);
     return 0;
 }
 
@@ -1278,6 +1323,12 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
 
 }  // namespace
 
+int release_device_streams(int dev)
+{
+    if (dev < 0 || dev >= 64) { set_error("release_device_streams: device index out of range"); return SGPR_E_ARG; }
+    return release_streams(dev);
+}
+
 int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st)
 {
     if (n < 0 || (n > 0 && lda < (size_t)n)) { set_error("potrf: bad n / lda"); return SGPR_E_ARG; }
@@ -1363,9 +1414,20 @@ static double *solve_pub(int n, const void *work)
 // (a bounded spin ran out: a bug or a device problem, never a property of the matrix)?  `host8` = the 8 state
 // words copied back by the caller (null when the strip kernels were not used for this order).
 bool trsv_uses_strips(int n, const double *L, size_t ldl) { return use_strips(n, L, ldl); }
+
+// Waits for the stream and reports a strip solve that gave up on a hand-off (never a property of the matrix).
+int solve_status(int n, const double *L, size_t ldl, const void *work, hipStream_t st)
+{
+    if (n <= 0 || !use_strips(n, L, ldl)) { SGPR_HIP(hipStreamSynchronize(st)); return 0; }
+    int h[8] = {};
+    SGPR_HIP(hipMemcpyAsync(h, solve_state(n, work), sizeof(h), hipMemcpyDeviceToHost, st));
+    SGPR_HIP(hipStreamSynchronize(st));
+    if (h[2] || h[6]) { set_error("triangular solve: a hand-off between strips timed out"); return SGPR_E_HIP; }
+    return 0;
+}
 const int *trsv_state(int n, const void *work) { return solve_state(n, work); }
 
-int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st)
+int potrs_vec(int n, const double *L, size_t ldl, void *work, double *b, hipStream_t st)
 {
     if (n <= 0) return 0;
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};
@@ -1404,7 +1466,7 @@ int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, s
 }
 
 // one-sided solve: b := L^-1 b (trans = 0) or L^-T b (trans = 1)
-int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st)
+int trsv(int n, const double *L, size_t ldl, void *work, double *b, int trans, hipStream_t st)
 {
     if (n <= 0) return 0;
     Ctx c{const_cast<double *>(static_cast<const double *>(work)), nullptr, st};

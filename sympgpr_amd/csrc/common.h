@@ -61,6 +61,8 @@ int applymap(int family, int mode, int nm, int ntest, int n0, const double *xtr,
 int gram_nd(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa, size_t ldxa,
             const double *hyp, int nhyp, double *K, size_t ld, size_t rstride, size_t cstride, long diag_off,
             double noise, hipStream_t st);
+int gram_nd_sel(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa, size_t ldxa,
+                const double *hyp, int nhyp, double *K, size_t ld, const long *roff, const long *coff, hipStream_t st);
 int predict_nd(int family, int d, int m, const double *Xt, size_t ldxt, int n0, const double *Xtr, size_t ldxtr,
                const double *hyp, int nhyp, const double *alpha, double *out, hipStream_t st);
 
@@ -94,13 +96,17 @@ inline int info_status(int info)
 }
 size_t potrf_workspace(int n);
 int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st);
+int release_device_streams(int dev);   // drain + destroy the streams potrf created on `dev` (they come back on demand)
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
              hipStream_t st);
-int potrs_vec(int n, const double *L, size_t ldl, const void *work, double *b, hipStream_t st);
+// One-right-hand-side solves keep their hand-off words (tickets, progress, the published segments) IN the workspace: one
+// solve per workspace at a time (two solves against one factor from two streams need two copies of the workspace).
+int potrs_vec(int n, const double *L, size_t ldl, void *work, double *b, hipStream_t st);
+int solve_status(int n, const double *L, size_t ldl, const void *work, hipStream_t st);   // syncs st; SGPR_E_HIP if a strip solve gave up
 int trsm_rl(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work, hipStream_t st);  // B := B L^-1
 int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, size_t ldb, int nrhs, double *scratch,
               hipStream_t st);  // B (n x nrhs) := L^-T L^-1 B; scratch: nrhs x n doubles
-int trsv(int n, const double *L, size_t ldl, const void *work, double *b, int trans, hipStream_t st);
+int trsv(int n, const double *L, size_t ldl, void *work, double *b, int trans, hipStream_t st);
 bool trsv_uses_strips(int n, const double *L, size_t ldl);      // potrs_vec / trsv take the one-launch strip kernels
 const int *trsv_state(int n, const void *work);                 // their 8 state words: [2], [6] != 0 = a hand-off timed out
 int leaf_probe(double *A, size_t lda, double *inv, int *dinfo, unsigned long long *stamps, hipStream_t st);

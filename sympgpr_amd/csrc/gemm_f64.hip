@@ -18,6 +18,7 @@
 //     4*reg+(lane>>4) = n, so every C access of a 16-lane quarter is one full 128-B line.
 //     (fp64 C/D layout: col = lane&15, row = (lane>>4) + 4*reg -- NOT the f32 map.)
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -38,7 +39,7 @@ namespace {
 struct ProfRec { double flop; int big; int m, n, k, lower, overlap; };
 struct Prof {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};       // read outside the mutex on the launch path
     std::vector<hipEvent_t> pool;      // 2 * PROF_POOL events, created once per process
     std::vector<ProfRec> recs;         // record i uses pool[2 i], pool[2 i + 1]
     long dropped = 0;                  // launches beyond the pool (not timed)
@@ -139,9 +140,9 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
     // profile window open: take the next event pair of the pool (none left: the launch goes untimed)
     int slot = -1;
     ProfRec rec{};
-    if (g_prof.on) {
+    if (g_prof.on.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(g_prof.mu);
-        if (g_prof.on) {
+        if (g_prof.on.load(std::memory_order_relaxed)) {
             if ((int)g_prof.recs.size() < PROF_POOL) {
                 // algorithmic flop of this launch: 2k per updated element (lower: on/below the diagonal)
                 double elems = (double)m * n;

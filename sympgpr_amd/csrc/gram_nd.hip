@@ -26,6 +26,8 @@ struct NdArgs {
     size_t ldxb, ldxa;
     double *K;
     size_t ld, rstride, cstride;   // element distance between consecutive row / column blocks
+    int sel;                       // 1: block (a, b) goes to K + roff[a] + coff[b] * ld instead, skipped when either is < 0
+    long roff[6], coff[6];
     long diag_off;
     double noise, sig;
     double l2[6], inv_l2[6], inv_l4[6];
@@ -96,7 +98,12 @@ __global__ __launch_bounds__(NT) void gram_nd_kernel(const NdArgs a)
         xb0[m] = v0 ? a.Xb[(size_t)i + (size_t)m * a.ldxb] : 0.0;
         xb1[m] = v1 ? a.Xb[(size_t)i + 1 + (size_t)m * a.ldxb] : 0.0;
     }
-    const bool vec = (i0 + NTI <= a.mi) && (((a.ld | a.rstride | a.cstride) & 1) == 0) && (((uintptr_t)a.K & 15) == 0);
+    bool even = ((a.ld | a.rstride | a.cstride) & 1) == 0;
+    if (a.sel) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) even = even && ((a.roff[c] & 1) == 0 || a.roff[c] < 0);
+    }
+    const bool vec = (i0 + NTI <= a.mi) && even && (((uintptr_t)a.K & 15) == 0);
     const long d0 = (long)i + a.diag_off;
     for (int jj = 0; jj < nj; ++jj) {
         double g0[D], nh0[D], g1[D], nh1[D], arg0[D], arg1[D], E0[D], E1[D];
@@ -114,7 +121,9 @@ __global__ __launch_bounds__(NT) void gram_nd_kernel(const NdArgs a)
                 const double off1 = (FAM == SGPR_FAM_B) ? 0.0 : -E1[ca] * (g1[ca] * g1[cb]);
                 const double k0 = (ca == cb) ? __builtin_fma(E0[ca], nh0[ca], n0) : off0;
                 const double k1 = (ca == cb) ? __builtin_fma(E1[ca], nh1[ca], n1) : off1;
-                double *dst = a.K + (size_t)ca * a.rstride + (size_t)i + ((size_t)cb * a.cstride + (size_t)j) * a.ld;
+                if (a.sel && (a.roff[ca] < 0 || a.coff[cb] < 0)) continue;      // block not wanted by this call
+                double *dst = a.sel ? a.K + (size_t)a.roff[ca] + (size_t)i + ((size_t)a.coff[cb] + (size_t)j) * a.ld
+                                    : a.K + (size_t)ca * a.rstride + (size_t)i + ((size_t)cb * a.cstride + (size_t)j) * a.ld;
                 if (vec) {
                     *reinterpret_cast<double2_t *>(dst) = double2_t{k0, k1};
                 } else {
@@ -209,6 +218,33 @@ int gram_nd(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, co
     if (mi <= 0 || mj <= 0) return 0;
     a.mi = mi; a.mj = mj; a.Xb = Xb; a.Xa = Xa; a.ldxb = ldxb; a.ldxa = ldxa;
     a.K = K; a.ld = ld; a.rstride = rstride; a.cstride = cstride; a.diag_off = diag_off; a.noise = noise;
+    const dim3 grid((mi + NTI - 1) / NTI, (mj + NTJ - 1) / NTJ);
+    if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
+    return dispatch_nd(family, d, [&](auto fam, auto dd) {
+        hipLaunchKernelGGL((gram_nd_kernel<decltype(fam)::value, decltype(dd)::value>), grid, dim3(NT), 0, st, a);
+        SGPR_CHECK_LAUNCH();
+        return 0;
+    });
+}
+
+// the same pairs, but only the blocks (a, b) with roff[a] >= 0 and coff[b] >= 0, block (a, b) at K + roff[a] + coff[b] * ld
+// (a block-cyclic rank whose coordinate blocks hold different points: sympgpr_amd/dist.py)
+int gram_nd_sel(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa, size_t ldxa,
+                const double *hyp, int nhyp, double *K, size_t ld, const long *roff, const long *coff, hipStream_t st)
+{
+    NdArgs a{};
+    int rc = fill_args(family, d, hyp, nhyp, a);
+    if (rc) return rc;
+    if (mi <= 0 || mj <= 0) return 0;
+    if (!roff || !coff) { set_error("gram_nd_sel: null offsets"); return SGPR_E_ARG; }
+    a.mi = mi; a.mj = mj; a.Xb = Xb; a.Xa = Xa; a.ldxb = ldxb; a.ldxa = ldxa;
+    a.K = K; a.ld = ld; a.rstride = 0; a.cstride = 0; a.diag_off = 1L << 60; a.noise = 0.0;
+    a.sel = 1;
+    bool any = false;
+    for (int c = 0; c < 2 * d; ++c) { a.roff[c] = roff[c]; a.coff[c] = coff[c]; }
+    for (int c = 0; c < 2 * d; ++c)
+        for (int e = 0; e < 2 * d; ++e) any = any || (roff[c] >= 0 && coff[e] >= 0);
+    if (!any) return 0;
     const dim3 grid((mi + NTI - 1) / NTI, (mj + NTJ - 1) / NTJ);
     if (grid.y > 65535) { set_error("too many pair columns for one launch"); return SGPR_E_ARG; }
     return dispatch_nd(family, d, [&](auto fam, auto dd) {

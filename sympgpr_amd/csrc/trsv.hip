@@ -219,7 +219,13 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
                 known = r > q + 1 ? r : q + 1;
             } else {
                 const double seg = have_next ? seg_next : (tid < LEAF ? load_sc1(seg_ptr(q) + tid) : 0.0);
-                if (tid < LEAF) vec[q & 1][tid] = seg;
+                if (tid < LEAF) {
+                    // the progress counter said this segment is there; if the sentinel is still what comes back, the
+                    // visibility assumption of the fence-free hand-off has failed: report it, do not feed NaNs to alpha
+                    if ((unsigned long long)__double_as_longlong(seg) == UNPUBLISHED)
+                        __hip_atomic_store((gi32 *)(a.state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vec[q & 1][tid] = seg;
+                }
                 __syncthreads();
             }
             // prefetch the following segment when it is known to be there
@@ -319,7 +325,8 @@ __global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
         if (TRSV_DBG && a.dbg && tid == 0) a.dbg[4 * tk + 2] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                      // every wave's part is out; LDS is reused by the next strip
-        if (tid == 0) __hip_atomic_store((gi32 *)(a.state + 1), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a maximum, not an overwrite: strips finish in dependency order, but nothing here should rest on that)
+        if (tid == 0) (void)__hip_atomic_fetch_max((gi32 *)(a.state + 1), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sh[1]) return;
         if (known < tk + 1) known = tk + 1;
         __syncthreads();

@@ -78,11 +78,30 @@ class HipOps:
     def work_size(self, nb):
         return (self.lib.sgpr_potrf_workspace(nb) + 7) // 8  # in doubles
 
+    def inv_size(self, nb):
+        """leading doubles of the factor workspace that hold the leaf inverses: all a peer needs beside L_KK"""
+        return self.lib.sgpr_potrf_inverses_bytes(nb) // 8
+
+    def solve_status(self, nb, Lkk, work):
+        """0, or 1 when a one-launch triangular solve on this workspace gave up on a hand-off (waits for the stream)"""
+        rc = self.lib.sgpr_solve_status_dev(nb, self._p(Lkk), nb, self._p(work), self.stream())
+        if rc == L.E_HIP:
+            return 1
+        L.check(rc, "sgpr_solve_status_dev")
+        return 0
+
     def gram_nd(self, fam, d, mi, mj, Xb, Xa, hyp, A, ld):
         """(2d)^2 blocks of mi x mj for d canonical pairs; Xb (mi x 2d), Xa (mj x 2d) column-major."""
         hyp = L.f64(hyp)
         L.check(self.lib.sgpr_gram_nd_dev(L.family_id(fam), d, mi, mj, self._p(Xb), mi, self._p(Xa), mj, L.dptr(hyp),
                                           len(hyp), self._p(A), ld, mi, mj, 0, 0.0, self.stream()), "sgpr_gram_nd_dev")
+
+    def gram_nd_sel(self, fam, d, mi, mj, Xb, Xa, hyp, A, ld, roff, coff):
+        """the same pairs, only the blocks (a, b) with roff[a] >= 0 and coff[b] >= 0, at A + roff[a] + coff[b] * ld"""
+        hyp = L.f64(hyp)
+        ro, co = (C.c_long * (2 * d))(*roff), (C.c_long * (2 * d))(*coff)
+        L.check(self.lib.sgpr_gram_nd_sel_dev(L.family_id(fam), d, mi, mj, self._p(Xb), mi, self._p(Xa), mj, L.dptr(hyp),
+                                              len(hyp), self._p(A), ld, ro, co, self.stream()), "sgpr_gram_nd_sel_dev")
 
     def gram_pairs(self, fam, mi, mj, xb, yb, xa, ya, hyp, A, offs, ld, flags):
         """offs: element offsets of the qq / Pq / qP / PP parts inside A (or None)."""
@@ -151,10 +170,9 @@ class DistFit:
         self.N = len(x)
         self.n = 2 * self.d * self.N
         # Block size: the largest divisor of N that does not exceed the request and is a multiple of the
-        # 128-row leaf (any divisor for small test problems).  One pair per point (the reference's layout)
-        # takes any N / nb; d > 1 needs N / nb divisible by both grid dimensions (see build()).
-        lcm = self.pr * self.pc // math.gcd(self.pr, self.pc)
-        self.nb = self._pick_nb(self.N, nb, 1 if self.d == 1 else lcm)
+        # 128-row leaf (any divisor for small test problems); any N / nb, for one pair per point and for d > 1
+        # alike (see build()).
+        self.nb = self._pick_nb(self.N, nb, 1)
         nb = self.nb
         self.nbk = self.n // nb
         nbN = self.N // nb
@@ -169,9 +187,13 @@ class DistFit:
         # local matrix, column-major (mloc x nloc), as a flat tensor
         self.A = ops.empty(self.mloc * self.nloc)
         self.A2 = self.A.view(self.nloc, self.mloc)            # [local col, local row]
-        self.Lkk = ops.empty(nb * nb)
+        # L_KK and the factor workspace back to back: [L_KK | leaf inverses | scratch] -- the diagonal block and the
+        # inverses of its leaves travel down the process column as ONE message (the first nb^2 + inv doubles)
+        self.inv_size = ops.inv_size(nb) if hasattr(ops, "inv_size") else ops.work_size(nb)
+        self._kkbuf = ops.empty(nb * nb + ops.work_size(nb))
+        self.Lkk = self._kkbuf[:nb * nb]
+        self.wbuf = self._kkbuf[nb * nb:]
         self.work = {}                                         # K -> leaf inverses of L_KK (owner only)
-        self.wbuf = ops.empty(ops.work_size(nb))
         self.info_t = ops.zeros(2, dtype=torch.int32)
         # process-column / process-row groups (every rank creates all of them, same order)
         self.col_groups = [dist.new_group([q + c * self.pr for q in range(self.pr)]) for c in range(self.pc)]
@@ -207,13 +229,34 @@ class DistFit:
                               if blocks else np.zeros(0, dtype=np.int64))
         ld = self.mloc
         if self.X is not None:
-            # d pairs: the same row / column selection in each of the 2d coordinate blocks
-            rsel = sel([I for I in self.rows if I < nbN])
-            csel = sel([J for J in self.cols if J < nbN])
-            mi, mj = len(rsel), len(csel)
-            Xb = dev(np.asfortranarray(self.X[rsel]).T.copy()).reshape(-1)   # (mi x 2d) column-major, flat
-            Xa = dev(np.asfortranarray(self.X[csel]).T.copy()).reshape(-1)
-            ops.gram_nd(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld)
+            # d pairs per point: global block row I belongs to coordinate a = I // (N/nb) and point-block I % (N/nb).
+            # When N/nb is a multiple of the grid dimension every coordinate block of this rank selects the same
+            # points (one launch writes all (2d)^2 blocks); otherwise the selections differ from coordinate to
+            # coordinate, and one launch per PAIR of distinct selections writes the blocks that belong to it.
+            D = 2 * self.d
+
+            def groups(blocks):
+                """per coordinate: (tuple of point-blocks, local offset in blocks)"""
+                out, pos = [], 0
+                for a in range(D):
+                    mine = tuple(B - a * nbN for B in blocks if B // nbN == a)
+                    out.append((mine, pos))
+                    pos += len(mine)
+                return out
+
+            rg, cg = groups(self.rows), groups(self.cols)
+            for R in sorted(set(g[0] for g in rg if g[0])):
+                for Cc in sorted(set(g[0] for g in cg if g[0])):
+                    rsel, csel = sel(list(R)), sel(list(Cc))
+                    mi, mj = len(rsel), len(csel)
+                    Xb = dev(np.asfortranarray(self.X[rsel]).T.copy()).reshape(-1)   # (mi x 2d) column-major, flat
+                    Xa = dev(np.asfortranarray(self.X[csel]).T.copy()).reshape(-1)
+                    if all(g[0] == R for g in rg) and all(g[0] == Cc for g in cg):
+                        ops.gram_nd(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld)
+                    else:
+                        roff = [g[1] * nb if g[0] == R else -1 for g in rg]
+                        coff = [g[1] * nb if g[0] == Cc else -1 for g in cg]
+                        ops.gram_nd_sel(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld, roff, coff)
         else:
             rq, rP = sel([I for I in self.rows if I < nbN]), sel([I - nbN for I in self.rows if I >= nbN])
             cq, cP = sel([J for J in self.cols if J < nbN]), sel([J - nbN for J in self.cols if J >= nbN])
@@ -265,15 +308,15 @@ class DistFit:
             cand = torch.where(i64 > 0, i64 + K * nb, torch.where(i64 < 0, i64, torch.full_like(i64, self._BIG)))
             self.fail_t = torch.minimum(self.fail_t, cand)
             blk.copy_(self.Lkk.view(nb, nb))
-            self.work[K] = self.wbuf.clone()
+            self.work[K] = self.wbuf.clone()          # (the whole workspace: the solves keep their hand-off words in it)
         li0 = _count_le(K, pi, pr)            # first local block row with I > K
         m_p = self.mloc - li0 * nb
         if pj == kJ:
             src = self.grank(kI, kJ)
             if pr > 1:
-                dist.broadcast(self.Lkk, src=src, group=self.col_groups[kJ])
-                dist.broadcast(self.wbuf, src=src, group=self.col_groups[kJ])
-                self.comm_bytes += 8 * (self.Lkk.numel() + self.wbuf.numel()) * (self.rank != src)
+                msg = self._kkbuf[:nb * nb + self.inv_size]        # L_KK + its leaf inverses: one message
+                dist.broadcast(msg, src=src, group=self.col_groups[kJ])
+                self.comm_bytes += 8 * msg.numel() * (self.rank != src)
             if m_p > 0:
                 ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, li0 * nb + lj_K * nb * self.mloc, self.mloc)
         nrow_blk = len(self.rows) - li0
@@ -429,6 +472,7 @@ class DistFit:
         pend = ops.zeros(self.mloc)
         vec = ops.empty(nb)
         logdet = ops.zeros(1)
+        gave_up = 0          # strip solves on this rank that ran out of patience on a hand-off (see _solve_status)
         # forward: y_K = L_KK^-1 (b_K - sum_{J<K} L(K,J) y_J)
         for K in range(self.nbk):
             kI, kJ = K % pr, K % pc
@@ -442,6 +486,7 @@ class DistFit:
                 Lkk = self._diag_block(K)
                 logdet += torch.log(Lkk.view(nb, nb).diagonal()).sum()
                 ops.trsv(nb, Lkk, self.work[K], vec, 0)
+                gave_up += self._solve_status(nb, Lkk, self.work[K])
             dist.broadcast(vec, src=owner, group=self.group)
             b2[K].copy_(vec)
             if pj == kJ:
@@ -468,12 +513,23 @@ class DistFit:
             if self.rank == owner:
                 vec.add_(b2[K])
                 ops.trsv(nb, self._diag_block(K), self.work[K], vec, 1)
+                gave_up += self._solve_status(nb, self.Lkk, self.work[K])
             dist.broadcast(vec, src=owner, group=self.group)
             b2[K].copy_(vec)
-        dist.all_reduce(logdet, op=dist.ReduceOp.SUM, group=self.group)
+        # one reduction carries the log-determinant and the count of solves that gave up (never silently NaN)
+        tail = torch.cat([logdet, torch.full_like(logdet, float(gave_up))])
+        dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=self.group)
+        logdet = tail[:1]
+        if float(tail[1].item()) > 0:
+            raise L.SympGPRError("a triangular solve gave up on a hand-off between two workgroups on some rank")
         self.alpha = b
         self.nll = float((0.5 * torch.dot(self.z, b) + logdet[0]).item())
         return b
+
+    def _solve_status(self, nb, Lkk, work):
+        """the strip solves bound their waits; a solve that gave up is reported through the solve's last reduction"""
+        fn = getattr(self.ops, "solve_status", None)
+        return fn(nb, Lkk, work) if fn else 0
 
     def run(self):
         self.build()

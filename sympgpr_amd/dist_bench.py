@@ -8,6 +8,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+STAGE = ["start"]      # where this rank is (bench.py names it when a collective times out or a rank fails)
+
 
 def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_pairs=None, cpu_baseline=None):
     from .dist import DistFit, HipOps, grid_shape
@@ -36,14 +38,17 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
     def step(timed):
         if timed:
             ev[0].record()
+        STAGE[0] = "gram build"
         fit.build()
         if timed:
             ev[1].record()
+        STAGE[0] = "factor (panel exchange on the row / column communicators)"
         info = fit.factor()
         if info:
             raise np.linalg.LinAlgError("leading minor %d not positive definite" % info)
         if timed:
             ev[2].record()
+        STAGE[0] = "solve (row / column reduces + world broadcasts)"
         fit.solve()
         if timed:
             ev[3].record()
@@ -51,6 +56,7 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
     for _ in range(args.warmup):
         step(False)
     stage = np.zeros(3)
+    STAGE[0] = "barrier before the timed steps"
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -63,7 +69,17 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
     st = torch.tensor(stage / max(args.steps, 1), dtype=torch.float64, device=dev)
     dist.all_reduce(st, op=dist.ReduceOp.MAX)
     ms_per_step = float(dt.item()) / args.steps * 1e3
+    my_stage = stage / max(args.steps, 1)
     stage = st.cpu().numpy()
+    STAGE[0] = "gathering the per-rank records"
+    # what every rank saw: device, PCI bus id, its own factor-stage time (the driver checks that N ranks really were
+    # N devices, and how far apart they ran)
+    props = torch.cuda.get_device_properties(dev)
+    bus = getattr(props, "pci_bus_id", None)
+    rec = [None] * world
+    dist.all_gather_object(rec, {"rank": rank, "device_index": local_rank, "device": props.name,
+                                 "pci_bus_id": int(bus) if bus is not None else None,
+                                 "uuid": str(getattr(props, "uuid", "")), "factor_ms": float(my_stage[1])})
     cb = torch.tensor([float(fit.comm_bytes)], dtype=torch.float64, device=dev)   # bytes this rank received
     cb_max, cb_sum = cb.clone(), cb.clone()
     dist.all_reduce(cb_max, op=dist.ReduceOp.MAX)
@@ -78,6 +94,12 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
         step(False)
         torch.cuda.synchronize()
         L_.check(ops.lib.sgpr_profile_end(L_.dptr(prof)))
+    # every rank's MFMA-kernel rate (all launches of its local trailing updates)
+    n_mine, fl_mine, ms_mine = prof[0] + prof[8], prof[1] + prof[9], prof[2] + prof[10]
+    mine = torch.tensor([fl_mine / (ms_mine * 1e-3) / 1e12 if ms_mine > 0 else 0.0], dtype=torch.float64, device=dev)
+    ach_min, ach_max = mine.clone(), mine.clone()
+    dist.all_reduce(ach_min, op=dist.ReduceOp.MIN)
+    dist.all_reduce(ach_max, op=dist.ReduceOp.MAX)
 
     # parity evidence: residual of Ky alpha = z on a sample of rows, rebuilt from the inputs
     a = fit.alpha.cpu().numpy()
@@ -110,7 +132,8 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
             "metric": metric,
             "value": chol_flop / (ms_per_step * 1e-3) / 1e12,
             "unit": "TFLOP/s (n^3/3 flop over the whole step: Gram build + Cholesky + solve)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": world, "rccl_world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" + (" -- REHEARSAL: all ranks on one card, collectives over gloo (not a multi-GPU measurement)"
                                    if dist.get_backend() == "gloo" else ""),
@@ -122,6 +145,9 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
             "gram_gb_s": 8.0 * n * n / (stage[0] * 1e-3) / 1e9, "gram_ms": stage[0],
             "chol_tflops": chol_flop / (stage[1] * 1e-3) / 1e12, "chol_ms": stage[1],
             "solve_ms": stage[2], "residual_Ky_alpha_minus_z": resid, "nll": fit.nll,
+            "ranks": rec,
+            "factor_tflops_per_rank_min_max": [chol_flop / (max(r["factor_ms"] for r in rec) * 1e-3) / 1e12 / world,
+                                               chol_flop / (min(r["factor_ms"] for r in rec) * 1e-3) / 1e12 / world],
             "panel_bytes_received_per_step": {"max_over_ranks": float(cb_max.item()), "sum_over_ranks": float(cb_sum.item()),
                                               "note": "row broadcast along the process row + column exchange down the "
                                                       "process column + L_KK and its leaf inverses; a rank receives "
@@ -135,6 +161,7 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
                                "traffic": None, "traffic_source": None,
                                "timing": "one untimed extra step, HIP-event pair per launch on rank 0",
                                "launches": int(n_l), "flop_per_launch": fl / n_l, "avg_launch_ms": ms_l / n_l,
+                               "achieved_min_max_over_ranks": [float(ach_min.item()), float(ach_max.item())],
                                "per_gpu_factor_stage_tflops": chol_flop / (stage[1] * 1e-3) / 1e12 / world}
         else:
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (local trailing updates)",

@@ -1,33 +1,37 @@
 """Host-array front-ends of the C ABI (NumPy in, NumPy out).  Each call stages through HBM;
 large problems should use ``fit.SympFit`` which keeps K on the device."""
 import contextlib
+import threading
 
 import numpy as np
 
 from . import _lib as L
 
-_FAMILY = "A"
+_DEFAULT_FAMILY = "A"
+_tls = threading.local()      # the selection belongs to the calling thread: two threads fitting different examples
+                              # (a Henon-Heiles fit beside a tokamak fit) must not flip each other's kernels
 
 
 def set_family(fam):
     """Select which generated kernels file of the reference is mirrored (default "A":
     periodic x SE, python/05_tokamak/SympGPR/kernels.f90).  The reference selects it by
-    which kernels*.f90 was compiled into the `kernels` / `sympgpr` module."""
-    global _FAMILY
+    which kernels*.f90 was compiled into the `kernels` / `sympgpr` module.
+
+    The selection is per THREAD; a thread that never selected one sees the default "A"."""
     if fam not in L.FAMILIES:
         raise ValueError("family must be one of %s" % sorted(L.FAMILIES))
-    _FAMILY = fam
+    _tls.family = fam
 
 
 def get_family():
-    return _FAMILY
+    return getattr(_tls, "family", _DEFAULT_FAMILY)
 
 
 @contextlib.contextmanager
 def family_scope(fam):
     """Temporarily select a kernel family (the per-example modules under sympgpr_amd/examples
     each correspond to one kernels*.f90 of the reference)."""
-    old = _FAMILY
+    old = get_family()
     set_family(fam)
     try:
         yield
@@ -54,7 +58,7 @@ def build_k(x, y, x0, y0, hyp, K, family=None):
     _check_inout(K, (2 * n, 2 * n0))
     if len(x) < n or len(y) < n or len(x0) < n0 or len(y0) < n0:
         raise ValueError("coordinate arrays shorter than K's block size")
-    L.check(lib.sgpr_build_k_host(L.family_id(family or _FAMILY), n, n0, L.dptr(x), L.dptr(y), L.dptr(x0),
+    L.check(lib.sgpr_build_k_host(L.family_id(family or get_family()), n, n0, L.dptr(x), L.dptr(y), L.dptr(x0),
                                   L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(K), max(K.shape[0], 1)),
             "sgpr_build_k_host")
 
@@ -67,7 +71,7 @@ def buildkreg(x, y, x0, y0, hyp, K, family=None):
     _check_inout(K, (n, n0))
     if len(x) < n or len(y) < n or len(x0) < n0 or len(y0) < n0:
         raise ValueError("coordinate arrays shorter than K's shape")
-    L.check(lib.sgpr_buildkreg_host(L.family_id(family or _FAMILY), n, n0, L.dptr(x), L.dptr(y), L.dptr(x0),
+    L.check(lib.sgpr_buildkreg_host(L.family_id(family or get_family()), n, n0, L.dptr(x), L.dptr(y), L.dptr(x0),
                                     L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(K), max(n, 1)),
             "sgpr_buildkreg_host")
 
@@ -81,7 +85,7 @@ def kernel_eval(which, x_a, y_a, x_b, y_b, l, family=None):
     xa, ya, xb, yb = (np.ascontiguousarray(v).ravel() for v in (xa, ya, xb, yb))
     l = L.f64(l)
     out = np.empty(len(xa))
-    L.check(lib.sgpr_kernel_eval_host(L.family_id(family or _FAMILY), which, len(xa), L.dptr(xa), L.dptr(ya),
+    L.check(lib.sgpr_kernel_eval_host(L.family_id(family or get_family()), which, len(xa), L.dptr(xa), L.dptr(ya),
                                       L.dptr(xb), L.dptr(yb), L.dptr(l), len(l), L.dptr(out)),
             "sgpr_kernel_eval_host")
     return float(out[0]) if scalar else out.reshape(shape)
@@ -138,7 +142,7 @@ def build_dk(x, y, x0, y0, hyp, family=None):
     out = []
     for which in (0, 1):
         D = np.empty((2 * n0, 2 * n), order="F")
-        L.check(lib.sgpr_build_dk_host(L.family_id(family or _FAMILY), which, n, n0, L.dptr(x), L.dptr(y),
+        L.check(lib.sgpr_build_dk_host(L.family_id(family or get_family()), which, n, n0, L.dptr(x), L.dptr(y),
                                        L.dptr(x0), L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(D), max(2 * n0, 1)),
                 "sgpr_build_dk_host")
         out.append(D)
@@ -153,7 +157,7 @@ def build_dkreg(x, y, x0, y0, hyp, family=None):
     out = []
     for which in (0, 1):
         D = np.empty((n, n0), order="F")
-        L.check(lib.sgpr_build_dkreg_host(L.family_id(family or _FAMILY), which, n, n0, L.dptr(x), L.dptr(y),
+        L.check(lib.sgpr_build_dkreg_host(L.family_id(family or get_family()), which, n, n0, L.dptr(x), L.dptr(y),
                                           L.dptr(x0), L.dptr(y0), L.dptr(hyp), len(hyp), L.dptr(D), max(n, 1)),
                 "sgpr_build_dkreg_host")
         out.append(D)
@@ -172,7 +176,7 @@ def build_k_nd(X, X0, hyp, family=None):
     if X0.shape[1] != D or D % 2:
         raise ValueError("X and X0 must be (n, 2d) and (n0, 2d)")
     K = np.empty((D * n, D * n0), order="F")
-    L.check(lib.sgpr_build_k_nd_host(L.family_id(family or _FAMILY), D // 2, n, n0, L.dptr(X), max(n, 1), L.dptr(X0),
+    L.check(lib.sgpr_build_k_nd_host(L.family_id(family or get_family()), D // 2, n, n0, L.dptr(X), max(n, 1), L.dptr(X0),
                                      max(n0, 1), L.dptr(hyp), len(hyp), L.dptr(K), max(D * n, 1)),
             "sgpr_build_k_nd_host")
     return K

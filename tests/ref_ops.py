@@ -42,6 +42,14 @@ class RefOps:
         K = self.oracle.build_K_nd(fam, Xb.numpy().reshape(D, mi).T, Xa.numpy().reshape(D, mj).T, hyp)
         _mat(A, 0, D * mi, D * mj, ld)[:, :] = K
 
+    def gram_nd_sel(self, fam, d, mi, mj, Xb, Xa, hyp, A, ld, roff, coff):
+        D = 2 * d
+        K = self.oracle.build_K_nd(fam, Xb.numpy().reshape(D, mi).T, Xa.numpy().reshape(D, mj).T, hyp)
+        for a in range(D):
+            for b in range(D):
+                if roff[a] >= 0 and coff[b] >= 0:
+                    _mat(A, roff[a] + coff[b] * ld, mi, mj, ld)[:, :] = K[a * mi:(a + 1) * mi, b * mj:(b + 1) * mj]
+
     def potrf(self, nb, A, work, info):
         M = _mat(A, 0, nb, nb, nb)
         Lf, inf = scipy.linalg.lapack.dpotrf(np.tril(M), lower=1)

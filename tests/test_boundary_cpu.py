@@ -31,7 +31,7 @@ def test_ctypes_table_matches_header():
     from sympgpr_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_symbols()
     lib = _lib.load_library()
-    assert lib.sgpr_abi_version() == 1
+    assert lib.sgpr_abi_version() == 2
 
 
 def test_mirror_has_reference_call_surface():
@@ -190,3 +190,32 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "2"]
     assert "sympgpr_amd._lib" not in set(sys.modules) - before      # the product library was not even loaded
+
+
+def test_family_selection_is_per_thread():
+    """func.set_family / ops.family_scope select the mirrored kernels*.f90 for the CALLING thread only: a thread that
+    never selected one sees "A", and a scope in one thread does not leak into another."""
+    import threading
+    from sympgpr_amd import func, ops
+    seen = {}
+    ready, go = threading.Event(), threading.Event()
+
+    def other():
+        seen["fresh"] = ops.get_family()
+        func.set_family("C")
+        ready.set()
+        go.wait(10)
+        seen["after"] = func.get_family()
+
+    func.set_family("A")
+    with ops.family_scope("B"):
+        t = threading.Thread(target=other)
+        t.start()
+        assert ready.wait(10)
+        assert ops.get_family() == "B"          # the other thread's "C" did not land here
+        go.set()
+        t.join()
+    assert ops.get_family() == "A"
+    assert seen == {"fresh": "A", "after": "C"}
+    with pytest.raises(ValueError):
+        func.set_family("Z")

@@ -69,9 +69,11 @@ def _worker_nd(rank, world, port, N, nb, d, out):
         dist.destroy_process_group()
 
 
-def test_block_cyclic_two_pairs_per_point(oracle):
-    """BASELINE config 'synthetic d=2 ... 2-D block-cyclic': the distributed driver with d = 2."""
-    N, nb, d, world = 16, 4, 2, 4
+# the last three: N / nb is NOT a multiple of the grid dimensions -- a rank's coordinate blocks then hold different points
+# and the (2d)^2 blocks are written by one call per pair of distinct selections (sgpr_gram_nd_sel_dev)
+@pytest.mark.parametrize("world,N,nb,d", [(4, 16, 4, 2), (3, 16, 4, 2), (6, 20, 4, 2), (2, 12, 4, 3)])
+def test_block_cyclic_two_pairs_per_point(oracle, world, N, nb, d):
+    """BASELINE config 'synthetic d=2 ... 2-D block-cyclic': the distributed driver with d canonical pairs."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker_nd, args=(world, _free_port(), N, nb, d, out), nprocs=world, join=True)
@@ -79,6 +81,7 @@ def test_block_cyclic_two_pairs_per_point(oracle):
     X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
     z = rng.standard_normal(2 * d * N)
     a_o, _, _ = oracle.fit_nd("A", X, z, np.append(np.full(2 * d, 1.1), 1.0), 0.05)
+    assert len(out) == world
     for r in range(world):
         assert np.linalg.norm(out[r] - a_o) / np.linalg.norm(a_o) < 1e-11
 

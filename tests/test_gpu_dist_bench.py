@@ -26,5 +26,11 @@ def test_bench_two_ranks_on_one_card():
     assert d["n_gpus"] == 2 and d["config"]["grid"] == [2, 1] and d["config"]["order_n"] == 8192
     assert d["residual_Ky_alpha_minus_z"] < 1e-10
     assert d["roofline"]["launches"] > 0 and d["cpu_baseline"]["kind"] in ("reference", "port")
+    # algorithmic flop only (elements on / below the GLOBAL diagonal): a fraction above 1 means the count is wrong
+    assert 0.0 < d["roofline"]["frac"] <= 1.0, d["roofline"]
+    lo, hi = d["roofline"]["achieved_min_max_over_ranks"]
+    assert 0.0 < lo <= hi <= 78.6
+    assert d["rccl_world_size"] == 2 and len(d["ranks"]) == 2 and {r["rank"] for r in d["ranks"]} == {0, 1}
+    assert all(r["device_index"] == 0 for r in d["ranks"])          # the rehearsal: both ranks on cuda:0
     assert d["panel_bytes_received_per_step"]["sum_over_ranks"] > 0
     assert "REHEARSAL" in d["data"]

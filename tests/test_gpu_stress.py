@@ -113,3 +113,57 @@ def test_multiples_of_128_factor_and_solve(n):
     xr = scipy.linalg.cho_solve((Lr, True), b)
     assert np.linalg.norm(x - xr) <= 1e-10 * np.linalg.norm(xr)
     assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b) * np.linalg.cond(A)
+
+
+def test_three_threads_three_handles_order_16384(oracle):
+    """Forward progress with concurrent handles at the size where the panels are wide (n = 16384: 1024- and 512-wide
+    panels, up to 31 persistent workgroups each holding a CU): three threads factor three different problems at once,
+    twice.  Every panel kernel of the device runs on the one shared side stream (chol.hip, side_stream), so at most one
+    set of spinning strips is resident whatever the number of handles; each result must equal the same handle's
+    single-threaded result bit for bit (no atomics anywhere on the path) and satisfy Ky alpha = z on sampled rows
+    rebuilt by the oracle.  Then the per-device streams are released and come back on demand."""
+    import threading
+    import torch
+    from sympgpr_amd import _lib as L
+    from sympgpr_amd.fit import SympFit
+    N = 8192
+    rng = np.random.default_rng(16384)
+    probs = []
+    for i in range(3):
+        q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+        l = 2.0 * np.sqrt(12 * np.pi / N) * (1.0 + 0.1 * i)
+        probs.append((q, P, z, [l, l, 1.0], 1e-2 / l**2))
+    streams = [torch.cuda.Stream() for _ in probs]        # one stream per handle: the null stream would serialise them
+    fits = [SympFit("A", *p, stream=st.cuda_stream) for p, st in zip(probs, streams)]
+    try:
+        seq = [(f.run().alpha().copy(), f.nll()) for f in fits]
+        idx = rng.choice(N, 48, replace=False)
+        for (q, P, z, hyp, s2), (a, _) in zip(probs, seq):
+            Krows = oracle.build_K("A", q[idx], P[idx], q, P, hyp)          # rows (idx | N + idx) of K
+            rows = np.concatenate((idx, N + idx))
+            r = Krows @ a + s2 * a[rows] - z[rows]
+            assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(z[rows])
+        errs = []
+
+        def work(i):
+            try:
+                for _ in range(2):
+                    a, nll = fits[i].run().alpha(), fits[i].nll()
+                    assert np.array_equal(a, seq[i][0]), "thread %d: alpha differs from the single-threaded run" % i
+                    assert nll == seq[i][1]
+            except Exception as e:      # noqa: BLE001  (re-raised in the main thread)
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        torch.cuda.synchronize()
+        L.check(L.load_library().sgpr_release_device_streams(torch.cuda.current_device()))
+        a = fits[0].run().alpha()
+        assert np.array_equal(a, seq[0][0])
+    finally:
+        for f in fits:
+            f.close()
