@@ -171,6 +171,163 @@ __global__ __launch_bounds__(LT) void fit_batch_kernel(const BatchArgs a)
     }
 }
 
+// ---- mid-size problems: 256 < n <= 2048 (a CMA-ES generation at N = 512 ... 1024 points) --------------------------
+// Three launches for the whole batch: (1) every Ky_b, lower triangle, into an npad x npad image (npad = n rounded up to
+// 128; the padding is an identity block: det 1, alpha 0 there); (2) chol.hip's panel_batch_kernel: W = npad / 128
+// workgroups per problem run the leaf chain on their own matrix, problems side by side; (3) one workgroup per problem:
+// y = L^-1 z and alpha = L^-T y through the leaf inverses, and the negative log-likelihood.
+constexpr int MT = 256;                   // build: pair rows per tile (one per thread)
+constexpr int MJ = 16;                    // build: pair columns per tile
+constexpr int ST = 512;                   // solve: threads per problem
+
+struct MidArgs {
+    int nbatch, npts, n, npad, reg;
+    const double *x, *y, *z;              // nbatch x npts, nbatch x npts, nbatch x n
+    const KConst *kc;
+    const double *noise;
+    double *A;                            // problem b at A + b * npad * npad, ld = npad
+    const double *inv;                    // leaf inverses: problem b at inv + b * (npad / 128) * 128 * 128
+    double *alpha, *nll;
+    const int *info;
+};
+
+template <int FAM>
+__global__ __launch_bounds__(MT) void mid_build_kernel(const MidArgs a)
+{
+    __shared__ double sx[MJ], sy[MJ];
+    const int b = blockIdx.z, N = a.npts, t = threadIdx.x;
+    const int i0 = blockIdx.x * MT, j0 = blockIdx.y * MJ;
+    const size_t ld = (size_t)a.npad;
+    double *A = a.A + (size_t)b * ld * ld;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int r = a.n + t; r < a.npad; r += MT) A[r + r * ld] = 1.0;     // the padding's diagonal (the rest was cleared)
+    const bool tile_lower = i0 + MT - 1 >= j0;        // some (i, j) of the tile has i >= j
+    if (a.reg && !tile_lower) return;
+    const double *x = a.x + (size_t)b * N, *y = a.y + (size_t)b * N;
+    const int nj = min(MJ, N - j0);
+    if (t < nj) { sx[t] = x[j0 + t]; sy[t] = y[j0 + t]; }
+    __syncthreads();
+    const int i = i0 + t;
+    if (i >= N) return;
+    const KConst kc = a.kc[b];
+    const double noise = a.noise[b];
+    const double xi = x[i], yi = y[i];
+    if (a.reg) {
+        for (int jj = 0; jj < nj; ++jj) {
+            const int j = j0 + jj;
+            if (i < j) break;
+            double k = kc.sig * kern_eval<FAM, false>(sx[jj], sy[jj], xi, yi, kc);
+            if (i == j) k += noise;
+            A[i + j * ld] = k;
+        }
+        return;
+    }
+    for (int jj = 0; jj < nj; ++jj) {
+        const int j = j0 + jj;
+        double kxx, kxy, kyy;
+        pair_eval<FAM, false>(sx[jj], sy[jj], xi, yi, kc, kxx, kxy, kyy);
+        if (i == j) { kxx += noise; kyy += noise; }
+        A[(N + i) + j * ld] = kxy;                     // Pq block: always below the diagonal
+        if (i >= j) {
+            A[i + j * ld] = kxx;
+            A[(N + i) + (N + j) * ld] = kyy;
+        }
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;      // lane 0 holds the sum
+}
+
+__global__ __launch_bounds__(ST) void mid_solve_kernel(const MidArgs a)
+{
+    __shared__ double r[16 * LEAF];        // the running right-hand side, then y, then alpha
+    __shared__ double tmp[2 * LEAF];
+    __shared__ double red[ST / 64];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = a.n, npad = a.npad, W = npad / (int)LEAF;
+    const size_t ld = (size_t)npad;
+    const double *A = a.A + (size_t)b * ld * ld;
+    const double *inv = a.inv + (size_t)b * W * LEAF * LEAF;
+    const double *z = a.z + (size_t)b * n;
+    if (a.info[b] != 0) {                  // not positive definite: the host turns info into NaN / +inf
+        if (t == 0) a.nll[b] = __builtin_nan("");
+        if (a.alpha)
+            for (int i = t; i < n; i += ST) a.alpha[(size_t)b * n + i] = __builtin_nan("");
+        return;
+    }
+    for (int i = t; i < npad; i += ST) r[i] = i < n ? z[i] : 0.0;
+    __syncthreads();
+    // ---- y = L^-1 z, strip by strip: y_s = X_ss r_s, then r_t -= L_ts y_s for the rows below
+    for (int s = 0; s < W; ++s) {
+        const double *X = inv + (size_t)s * LEAF * LEAF;
+        {
+            // thread (i, h): half h of the k range of row i (lanes run over i: the loads of one k are contiguous)
+            const int i = t & 127, h = t >> 7;       // h = 0..3: quarters of k
+            double acc = 0.0;
+            const int k0 = h * 32, k1 = min(k0 + 32, i + 1);
+            for (int k = k0; k < k1; ++k) acc = __builtin_fma(X[i + k * LEAF], r[s * LEAF + k], acc);
+            // four partial sums per row: combine in a fixed order
+            for (int hh = 0; hh < 4; ++hh) {
+                if (h == hh) tmp[i] = hh == 0 ? acc : tmp[i] + acc;
+                __syncthreads();
+            }
+        }
+        if (t < (int)LEAF) r[s * LEAF + t] = tmp[t];
+        __syncthreads();
+        const int rows = npad - (s + 1) * (int)LEAF;
+        for (int q = t; q < rows; q += ST) {
+            const int row = (s + 1) * (int)LEAF + q;
+            const double *Ar = A + row + (size_t)s * LEAF * ld;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int k = 0; k < (int)LEAF; k += 2) {
+                acc0 = __builtin_fma(Ar[(size_t)k * ld], r[s * LEAF + k], acc0);
+                acc1 = __builtin_fma(Ar[(size_t)(k + 1) * ld], r[s * LEAF + k + 1], acc1);
+            }
+            r[row] -= acc0 + acc1;
+        }
+        __syncthreads();
+    }
+    // ---- alpha = L^-T y, from the last strip up: alpha_s = X_ss^T r_s, then r_j -= L(s, j)^T alpha_s for the columns left
+    for (int s = W - 1; s >= 0; --s) {
+        const double *X = inv + (size_t)s * LEAF * LEAF;
+        // column i of X_ss (entries k >= i) against r_s: one wave per column, lanes over k
+        for (int i = wave; i < (int)LEAF; i += ST / 64) {
+            double acc = 0.0;
+            for (int k = lane; k < (int)LEAF; k += 64)
+                if (k >= i) acc = __builtin_fma(X[k + i * LEAF], r[s * LEAF + k], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) tmp[i] = acc;
+        }
+        __syncthreads();
+        if (t < (int)LEAF) r[s * LEAF + t] = tmp[t];
+        __syncthreads();
+        const int cols = s * (int)LEAF;
+        for (int j = wave; j < cols; j += ST / 64) {
+            const double *Ac = A + (size_t)s * LEAF + (size_t)j * ld;      // rows of strip s in column j: contiguous
+            double acc = __builtin_fma(Ac[lane], r[s * LEAF + lane], Ac[lane + 64] * r[s * LEAF + lane + 64]);
+            acc = wave_sum(acc);
+            if (lane == 0) r[j] -= acc;
+        }
+        __syncthreads();
+    }
+    // ---- nll = z.alpha / 2 + sum log L_ii  (func.py:195)
+    double q = 0.0;
+    for (int i = t; i < n; i += ST) q += 0.5 * z[i] * r[i] + log(A[i + i * ld]);
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    if (t == 0) {
+        double v = 0.0;
+        for (int w = 0; w < ST / 64; ++w) v += red[w];
+        a.nll[b] = v;
+    }
+    if (a.alpha)
+        for (int i = t; i < n; i += ST) a.alpha[(size_t)b * n + i] = r[i];
+}
+
 // Device + pinned-host staging of one calling thread, grown on demand and kept: a call is then one H2D copy,
 // one launch and one D2H copy (nine hipMalloc / hipFree pairs and eight small pageable copies per call were
 // most of a single small fit's 230 us through a handle).
@@ -212,7 +369,76 @@ inline size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 
 }  // namespace
 
-int fit_batch_max_order() { return BMAX; }
+int fit_batch_max_order() { return potrf_batch_max_order(); }
+
+namespace {
+
+// problems of order 256 < n <= 2048: see the kernels above.  Chunks of problems share the scratch images.
+int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double *x, const double *y, const double *z,
+                  const double *hyp, int nhyp, const double *sig2n, double *alpha, double *nll, int *info)
+{
+    const int npad = (n + (int)LEAF - 1) / (int)LEAF * (int)LEAF, W = npad / (int)LEAF;
+    const size_t img = (size_t)npad * npad * 8, invb = (size_t)W * LEAF * LEAF * 8;
+    // at most ~6 GiB of images per chunk, at least one chip-full of strips (256 workgroups)
+    int chunk = (int)std::min<size_t>((size_t)nbatch, std::max<size_t>((256 + W - 1) / W, (6ull << 30) / img));
+    if (chunk > 16384) chunk = 16384;      // grid.z of the build launch
+    const size_t C = (size_t)chunk;
+    const size_t o_x = 0, o_y = o_x + up256(C * npts * 8), o_z = o_y + up256(C * npts * 8), o_kc = o_z + up256(C * n * 8),
+                 o_no = o_kc + up256(C * sizeof(KConst)), in_bytes = o_no + up256(C * 8);
+    const size_t o_al = 0, o_nll = o_al + up256(C * n * 8), o_info = o_nll + up256(C * 8), out_bytes = o_info + up256(C * sizeof(int));
+    const size_t o_A = 0, o_inv = o_A + up256(C * img), o_fl = o_inv + up256(C * invb), scr_bytes = o_fl + up256(potrf_batch_flag_bytes(chunk));
+    Arena &ar = t_arena;
+    int rc = ar.reserve(in_bytes + out_bytes + scr_bytes, in_bytes + out_bytes);
+    if (rc) return rc;
+    char *hin = ar.host, *hout = ar.host + in_bytes;
+    char *din = ar.dev, *dout = ar.dev + in_bytes, *dscr = ar.dev + in_bytes + out_bytes;
+    hipStream_t st = nullptr;
+    for (int b0 = 0; b0 < nbatch; b0 += chunk) {
+        const int nb = std::min(chunk, nbatch - b0);
+        const size_t B = (size_t)nb;
+        memcpy(hin + o_x, x + (size_t)b0 * npts, B * npts * 8);
+        memcpy(hin + o_y, y + (size_t)b0 * npts, B * npts * 8);
+        memcpy(hin + o_z, z + (size_t)b0 * n, B * n * 8);
+        KConst *kcs = reinterpret_cast<KConst *>(hin + o_kc);
+        double *noise = reinterpret_cast<double *>(hin + o_no);
+        for (int b = 0; b < nb; ++b) {
+            if ((rc = make_kconst(family, hyp + (size_t)(b0 + b) * nhyp, nhyp, &kcs[b]))) return rc;
+            noise[b] = std::fabs(sig2n[b0 + b]);
+        }
+        SGPR_HIP(hipMemcpyAsync(din, hin, in_bytes, hipMemcpyHostToDevice, st));
+        double *dA = reinterpret_cast<double *>(dscr + o_A), *dinv = reinterpret_cast<double *>(dscr + o_inv);
+        int *dinfo = reinterpret_cast<int *>(dout + o_info);
+        if (npad != n) SGPR_HIP(hipMemsetAsync(dA, 0, B * img, st));
+        MidArgs a{nb, npts, n, npad, reg, reinterpret_cast<double *>(din + o_x), reinterpret_cast<double *>(din + o_y),
+                  reinterpret_cast<double *>(din + o_z), reinterpret_cast<KConst *>(din + o_kc),
+                  reinterpret_cast<double *>(din + o_no), dA, dinv, alpha ? reinterpret_cast<double *>(dout + o_al) : nullptr,
+                  reinterpret_cast<double *>(dout + o_nll), dinfo};
+        const dim3 grid((npts + MT - 1) / MT, (npts + MJ - 1) / MJ, nb);
+        switch (family) {
+        case SGPR_FAM_A: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_A>, grid, dim3(MT), 0, st, a); break;
+        case SGPR_FAM_B: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_B>, grid, dim3(MT), 0, st, a); break;
+        case SGPR_FAM_C: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_C>, grid, dim3(MT), 0, st, a); break;
+        default:         hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_D>, grid, dim3(MT), 0, st, a); break;
+        }
+        SGPR_CHECK_LAUNCH();
+        if ((rc = potrf_batch(nb, npad, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF,
+                              reinterpret_cast<int *>(dscr + o_fl), dinfo, st)))
+            return rc;
+        hipLaunchKernelGGL(mid_solve_kernel, dim3(nb), dim3(ST), 0, st, a);
+        SGPR_CHECK_LAUNCH();
+        const size_t from = alpha ? 0 : o_nll;
+        SGPR_HIP(hipMemcpyAsync(hout + from, dout + from, out_bytes - from, hipMemcpyDeviceToHost, st));
+        SGPR_HIP(hipStreamSynchronize(st));
+        if (alpha) memcpy(alpha + (size_t)b0 * n, hout + o_al, B * n * 8);
+        memcpy(nll + b0, hout + o_nll, B * 8);
+        memcpy(info + b0, hout + o_info, B * sizeof(int));
+        for (int b = 0; b < nb; ++b)
+            if (info[b0 + b] < 0) return info_status(info[b0 + b]);     // a hand-off timed out: an error of the call
+    }
+    return 0;
+}
+
+}  // namespace
 
 // host buffers in, host buffers out; see include/sympgpr_hip.h (sgpr_fit_batch)
 int fit_batch(int family, int nbatch, int npts, const double *x, const double *y, const double *z, const double *hyp,
@@ -220,13 +446,14 @@ int fit_batch(int family, int nbatch, int npts, const double *x, const double *y
 {
     const int reg = (flags & SGPR_FIT_REG) ? 1 : 0;
     const int n = reg ? npts : 2 * npts;
-    if (nbatch < 0 || npts <= 0 || n > BMAX || !x || !y || !z || !hyp || !sig2n || !nll || !info ||
+    if (nbatch < 0 || npts <= 0 || n > potrf_batch_max_order() || !x || !y || !z || !hyp || !sig2n || !nll || !info ||
         (flags & ~(unsigned)SGPR_FIT_REG)) {
-        set_error("fit_batch: bad arguments (order per problem at most 256)");
+        set_error("fit_batch: bad arguments (order per problem at most 2048)");
         return SGPR_E_ARG;
     }
     if (nbatch == 0) return 0;
     if (family < SGPR_FAM_A || family > SGPR_FAM_D) { set_error("fit_batch: unknown kernel family"); return SGPR_E_ARG; }
+    if (n > BMAX) return fit_batch_mid(family, nbatch, npts, n, reg, x, y, z, hyp, nhyp, sig2n, alpha, nll, info);
     const size_t B = (size_t)nbatch;
     const int grid = nbatch < 1024 ? nbatch : 1024;
     const size_t per_wg = (size_t)BMAX * BMAX + 2 * (size_t)LEAF * LEAF + 2 * BMAX;

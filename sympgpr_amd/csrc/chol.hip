@@ -781,6 +781,41 @@ __global__ __launch_bounds__(LT) void panel_seq_kernel(const PanelSeq q)
     }
 }
 
+// Many independent factorisations of order <= PW_MAX leaves side by side in ONE launch (batch.hip: the population of a
+// CMA-ES generation, python/05_tokamak/Split_SympGPR/main.py:63-66): each problem is a single panel whose W diagonal strips
+// are W workgroups running the chain above on their own matrix.  Tickets in arrival order: ticket t is strip t % W of
+// problem t / W, so a strip only ever waits for strips with smaller tickets -- resident or finished, whatever number of
+// workgroups the chip holds at once.
+struct PanelBatch {
+    double *A;              // problem p at A + p * stride_a (column-major, lda), lower triangle filled
+    size_t stride_a, lda;
+    double *inv;            // leaf inverses of problem p at inv + p * stride_inv (W leaves)
+    size_t stride_inv;
+    int *flags;             // PFLAG_STRIDE ints per problem, zero on entry
+    int *info;              // per problem: 0, the 1-based failing minor, or PANEL_TIMEOUT
+    int *ticket;            // one int, zero on entry
+    int W, nbatch;
+};
+
+__global__ __launch_bounds__(LT) void panel_batch_kernel(const PanelBatch q)
+{
+    __shared__ double s[LEAF * ILD];
+    __shared__ int sh[2];
+    if (threadIdx.x == 0) sh[0] = atomicAdd(q.ticket, 1);
+    __syncthreads();
+    const int t = sh[0];
+    __syncthreads();
+    const int p = t / q.W, g = t - p * q.W;
+    if (p >= q.nbatch) return;
+    PanelArgs a{};
+    a.P = q.A + (size_t)p * q.stride_a; a.lda = q.lda;
+    a.W = a.R = a.G = q.W;
+    a.inv = q.inv + (size_t)p * q.stride_inv;
+    a.dinfo = q.info + p; a.goff = 0;
+    a.flags = q.flags + (size_t)p * PFLAG_STRIDE;
+    (void)panel_strip(a, g, s, sh);
+}
+
 inline int split(int n)
 {
     // first part: a multiple of LEAF close to n/2 (>= LEAF, < n)
@@ -1322,6 +1357,28 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
 }
 
 }  // namespace
+
+size_t potrf_batch_flag_bytes(int nbatch) { return ((size_t)nbatch * PFLAG_STRIDE + 1) * sizeof(int); }
+int potrf_batch_max_order() { return PW_MAX * (int)LEAF; }
+
+// nbatch lower Cholesky factorisations of order npad (a multiple of 128, <= potrf_batch_max_order()) in one launch;
+// `flags`: potrf_batch_flag_bytes(nbatch) bytes of scratch; info[p]: 0 or the 1-based failing minor of problem p
+int potrf_batch(int nbatch, int npad, double *A, size_t stride_a, size_t lda, double *inv, size_t stride_inv, int *flags,
+                int *info, hipStream_t st)
+{
+    if (nbatch < 0 || npad <= 0 || npad % LEAF != 0 || npad > PW_MAX * (int)LEAF || lda < (size_t)npad || (lda & 1) != 0 ||
+        ((uintptr_t)A & 15) != 0 || (stride_a & 1) != 0) {
+        set_error("potrf_batch: bad order / leading dimension / alignment");
+        return SGPR_E_ARG;
+    }
+    if (nbatch == 0) return 0;
+    SGPR_HIP(hipMemsetAsync(flags, 0, potrf_batch_flag_bytes(nbatch), st));
+    SGPR_HIP(hipMemsetAsync(info, 0, (size_t)nbatch * sizeof(int), st));
+    PanelBatch q{A, stride_a, lda, inv, stride_inv, flags, info, flags + (size_t)nbatch * PFLAG_STRIDE, npad / (int)LEAF, nbatch};
+    hipLaunchKernelGGL(panel_batch_kernel, dim3((unsigned)(nbatch * q.W)), dim3(LT), 0, st, q);
+    SGPR_CHECK_LAUNCH();
+    return 0;
+}
 
 int release_device_streams(int dev)
 {

@@ -96,6 +96,11 @@ inline int info_status(int info)
 }
 size_t potrf_workspace(int n);
 int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hipStream_t st);
+// batch.hip's mid-size path: nbatch factorisations of order npad (multiple of 128, <= potrf_batch_max_order()) in one launch
+size_t potrf_batch_flag_bytes(int nbatch);
+int potrf_batch_max_order();
+int potrf_batch(int nbatch, int npad, double *A, size_t stride_a, size_t lda, double *inv, size_t stride_inv, int *flags,
+                int *info, hipStream_t st);
 int release_device_streams(int dev);   // drain + destroy the streams potrf created on `dev` (they come back on demand)
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
              hipStream_t st);

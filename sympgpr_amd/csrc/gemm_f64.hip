@@ -100,6 +100,21 @@ int gemm_nt_bc(int m, int n, int k, double alpha, const double *A, size_t lda, c
                size_t ldb, double beta, double *C, size_t ldc, int lower, const int *bc,
                hipStream_t st)
 {
+    // Products deeper than 8192 run as back-to-back launches of <= 8192 columns each (C re-read per launch, negligible
+    // beside the flop), so that the 32 workgroups sharing a super-tile's operand panels restart in step instead of drifting
+    // apart over a 65536-deep loop.  Measured on one MI355X (profiles/r03/kmax.md): m = 65536 lower, k = 65536: 71.6 -> 72.6
+    // TFLOP/s (16384: 72.0), k = 32768: 71.5 -> 72.6; the n = 131072 step 70.0 -> 71.1.  SGPR_GEMM_KMAX=<k> overrides, 0 = off.
+    static const int kmax = [] { const char *e = getenv("SGPR_GEMM_KMAX"); return e ? atoi(e) : 8192; }();
+    if (kmax >= 128 && k > kmax) {
+        const int nchunk = (k + kmax - 1) / kmax;
+        const int step = ((k + nchunk - 1) / nchunk + 127) / 128 * 128;
+        for (int k0 = 0; k0 < k; k0 += step) {
+            const int rc = gemm_launch(m, n, std::min(step, k - k0), alpha, A + (size_t)k0 * lda, lda, B + (size_t)k0 * ldb, ldb,
+                                       k0 == 0 ? beta : 1.0, C, ldc, lower, bc, 0, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     return gemm_launch(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, lower, bc, 0, st);
 }
 

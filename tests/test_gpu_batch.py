@@ -136,14 +136,14 @@ def test_fit_batch_edges(oracle):
     import sympgpr_amd
     from sympgpr_amd import func
     from sympgpr_amd.fit import batch_max_order, fit_batch
-    assert batch_max_order() == 256
+    assert batch_max_order() == 2048
     al, nll, info = fit_batch("A", np.zeros((0, 5)), np.zeros((0, 5)), np.zeros((0, 10)), np.zeros((0, 3)), np.zeros(0))
     assert al.shape == (0, 10) and nll.shape == (0,) and info.shape == (0,)
     rng = np.random.default_rng(4)
     with pytest.raises(sympgpr_amd.SympGPRError):
-        fit_batch("A", rng.random((2, 129)), rng.random((2, 129)), rng.random((2, 258)), np.tile([0.5, 0.5, 1.0], (2, 1)), 1e-2)
-    # order 300 > 256: nll_chol_batch falls back to one handle per row
-    Np = 150
+        fit_batch("A", rng.random((2, 1025)), rng.random((2, 1025)), rng.random((2, 2050)), np.tile([0.5, 0.5, 1.0], (2, 1)), 1e-2)
+    # order 2100 > 2048: nll_chol_batch falls back to one handle per row
+    Np = 1050
     x = np.hstack((rng.uniform(0, 2 * np.pi, Np), rng.uniform(-3, 3, Np)))
     yv = rng.standard_normal(2 * Np)
     hyps = np.array([[0.4, 0.6, 1.0, 1e-2], [0.5, 0.7, 1.2, 2e-2]])
@@ -160,3 +160,66 @@ def test_fit_batch_edges(oracle):
     al, nll, info = fit_batch("A", X, Y, Z, np.tile([0.6, 0.8, 1.0], (B, 1)), 1e-2)
     assert np.all(info == 0) and np.isnan(nll[1]) and np.isfinite(nll[0]) and np.isfinite(nll[2])
     assert np.all(np.isfinite(al[0])) and np.all(np.isfinite(al[2]))
+
+
+@pytest.mark.parametrize("fam,n_pts,reg", [("A", 192, False), ("C", 250, False), ("A", 512, False), ("B", 700, False),
+                                           ("A", 1024, False), ("A", 300, True), ("C", 1024, True), ("A", 2048, True)])
+def test_fit_batch_mid_orders_vs_oracle(oracle, fam, n_pts, reg):
+    """orders 257 ... 2048 (three launches for the whole batch: build, W = ceil(n / 128) workgroups per problem running the
+    leaf chain side by side, one workgroup per problem for the solves): every problem against the oracle's fit; ragged
+    orders are padded with an identity block"""
+    from sympgpr_amd.fit import fit_batch
+    rng = np.random.default_rng(7 * n_pts + ord(fam) + reg)
+    n = n_pts if reg else 2 * n_pts
+    B = 3 if n > 1024 else 6
+    x, y, hyp, s2 = _problems(rng, B, n_pts, fam)
+    l = 2.0 * np.sqrt(12 * np.pi / n_pts)                  # lengths that keep cond(Ky) moderate at this density
+    hyp[:, :2] = l * rng.uniform(0.8, 1.25, (B, 2))
+    z = rng.standard_normal((B, n))
+    al, nll, info = fit_batch(fam, x, y, z, hyp, s2, reg=reg)
+    assert np.all(info == 0)
+    for b in range(B):
+        if reg:
+            Ky = oracle.buildKreg(fam, x[b], y[b], x[b], y[b], hyp[b]) + s2[b] * np.eye(n)
+            Lf = oracle.cholesky(Ky)
+            a_o = oracle.solve_cholesky(Lf, z[b])
+            nll_o = oracle.nll(Lf, z[b], a_o)
+        else:
+            a_o, nll_o, _ = oracle.fit(fam, x[b], y[b], z[b], hyp[b], s2[b], threads=4)
+        assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < 1e-9, (b, n)
+        assert nll[b] == pytest.approx(nll_o, rel=1e-10, abs=1e-10)
+
+
+def test_fit_batch_mid_population_and_failures(oracle):
+    """a CMA-ES generation at N = 512 points (order 1024): 24 hyper-parameter vectors over the same data in one call of
+    func.nll_chol_batch; a vector whose Ky is not positive definite (sig < 0) comes back +inf (info > 0, the LAPACK-style
+    index of the failing minor) and leaves its neighbours alone; more problems than the chip holds strips at once"""
+    from sympgpr_amd import func
+    from sympgpr_amd.fit import fit_batch
+    rng = np.random.default_rng(99)
+    Np = 512
+    x = np.hstack((rng.uniform(0, 2 * np.pi, Np), rng.uniform(-3, 3, Np)))
+    yv = rng.standard_normal(2 * Np)
+    l = 2.0 * np.sqrt(12 * np.pi / Np)
+    hyps = np.column_stack((l * rng.uniform(0.7, 1.4, 24), l * rng.uniform(0.7, 1.4, 24), rng.uniform(0.5, 2.0, 24),
+                            rng.uniform(1e-3, 1e-2, 24)))
+    hyps[7, 2] = -1.0                                    # Ky negative definite
+    func.set_family("A")
+    got = func.nll_chol_batch(hyps, x, yv, 2 * Np)
+    assert np.isposinf(got[7])
+    for b in (0, 6, 8, 23):
+        _, nll_o, _ = oracle.fit("A", x[:Np], x[Np:], yv, hyps[b, :-1], hyps[b, -1], threads=4)
+        assert got[b] == pytest.approx(nll_o, rel=1e-10)
+    # 80 problems of order 512 = 320 strips > 256 CUs: tickets keep every wait pointed at a resident workgroup
+    B, n_pts = 80, 256
+    X, Y = rng.uniform(0, 2 * np.pi, (B, n_pts)), rng.uniform(-3, 3, (B, n_pts))
+    Z = rng.standard_normal((B, 2 * n_pts))
+    l = 2.0 * np.sqrt(12 * np.pi / n_pts)
+    H = np.column_stack((l * rng.uniform(0.8, 1.25, B), l * rng.uniform(0.8, 1.25, B), np.ones(B)))
+    H[11, 2] = -1.0
+    al, nll, info = fit_batch("A", X, Y, Z, H, 1e-2)
+    assert info[11] == 1 and np.isnan(nll[11]) and np.all(np.delete(info, 11) == 0)
+    for b in (0, 10, 12, 79):
+        a_o, nll_o, _ = oracle.fit("A", X[b], Y[b], Z[b], H[b], 1e-2, threads=4)
+        assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < 1e-9
+        assert nll[b] == pytest.approx(nll_o, rel=1e-10)

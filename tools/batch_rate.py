@@ -3,7 +3,9 @@ nll_chol at a time as the unmodified drivers call it (a batch of one: one launch
 per call (round 1's path) and (b) the reference's CPU path for the same call
 (its compiled Fortran build_K from oracle/_ref + the SciPy cholesky / solve_triangular of
 python/functions/func.py:189-196, one thread, as the reference runs it).
-python tools/batch_rate.py [orders...]   (default 80 160)"""
+Orders above 256 take the mid-size path (three launches per batch: build, W workgroups per problem running the leaf chain
+side by side, one workgroup per problem for the solves); their batch sizes are a CMA-ES generation's (4, 16, 64).
+python tools/batch_rate.py [orders...]   (default 80 160 512 1024 2048)"""
 import os
 import sys
 import time
@@ -26,7 +28,7 @@ def cpu_nll(ref, x, y, z, hyp, s2):
 
 
 def main():
-    orders = [int(a) for a in sys.argv[1:]] or [80, 160]
+    orders = [int(a) for a in sys.argv[1:]] or [80, 160, 512, 1024, 2048]
     try:
         from threadpoolctl import threadpool_limits
         limit = threadpool_limits(limits=1)
@@ -40,19 +42,20 @@ def main():
     print("|---|---|---|---|---|---|")
     for n in orders:
         Np = n // 2
-        for B in (4, 64, 1024):
+        small = n <= 256
+        for B in ((4, 64, 1024) if small else (4, 16, 64)):
             x, y = rng.uniform(0, 2 * np.pi, (B, Np)), rng.uniform(-3, 3, (B, Np))
             z = rng.standard_normal((B, n))
             l = 2.0 * np.sqrt(12 * np.pi / Np)
             hyp = np.tile([l, l, 1.0], (B, 1))
             s2 = np.full(B, 1e-2 / l**2)
             fit_batch("A", x, y, z, hyp, s2)
-            reps = max(1, 2000 // B)
+            reps = max(1, 2000 // B) if small else 3
             t0 = time.perf_counter()
             for _ in range(reps):
                 _, nll, info = fit_batch("A", x, y, z, hyp, s2, want_alpha=False)
             tb = (time.perf_counter() - t0) / (reps * B)
-            m = min(B, 64)
+            m = min(B, 64 if small else 8)
             t0 = time.perf_counter()
             one = [func.nll_chol(np.append(hyp[b], s2[b]), np.hstack((x[b], y[b])), z[b], n) for b in range(m)]
             t1c = (time.perf_counter() - t0) / m
