@@ -39,7 +39,13 @@ extern "C" {
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
        SGPR_FAM_C = 2,   /* SE x SE                      : 03_henon_heiles/kernels_sq.f90        */
-       SGPR_FAM_D = 3 }; /* periodic, free period p      : 01_pendulum/implicit_period_unknown/kernels.f90 */
+       SGPR_FAM_D = 3,   /* periodic, free period p      : 01_pendulum/implicit_period_unknown/kernels.f90 */
+       SGPR_FAM_USER = 4 }; /* the user's kernel: GENERATED code only (tools/gen_kernels.py, USER_FAMILY; the step the
+                               reference performs with init_func.py:24-81).  As shipped: SE x SE a second time. */
+
+/* 1 when the family's hyper-parameter vector carries a period p between the lengths and sig -- family D, or a user kernel
+ * whose definition uses p: hyp = (lx, ly, p, sig), for d > 1 (lq_1..lq_d, lP_1..lP_d, p_1..p_d, sig); else 0 */
+int sgpr_family_has_p(int family);
 
 /* `which` of sgpr_kernel_eval: the four functions of a kernels*.f90 that enter K */
 enum { SGPR_K_KERN = 0, SGPR_K_DXDX0 = 1, SGPR_K_DYDY0 = 2, SGPR_K_DXDY0 = 3,

@@ -4,7 +4,7 @@ import os
 
 import numpy as np
 
-FAMILIES = {"A": 0, "B": 1, "C": 2, "D": 3}
+FAMILIES = {"A": 0, "B": 1, "C": 2, "D": 3, "USER": 4}   # USER: the generated-only slot (tools/gen_kernels.py)
 K_KERN, K_DXDX0, K_DYDY0, K_DXDY0 = 0, 1, 2, 3
 K_DLX, K_DLY = 4, 8
 K_DX, K_DY, K_DX0, K_DY0, K_DXDX0DY0, K_DYDY0DY0, K_DXDY0DY0 = 16, 17, 18, 19, 20, 21, 22
@@ -83,6 +83,7 @@ SIGNATURES = {
     "sgpr_potrf_workspace": (C.c_size_t, [C.c_int]),
     "sgpr_potrf_inverses_bytes": (C.c_size_t, [C.c_int]),
     "sgpr_release_device_streams": (C.c_int, [C.c_int]),
+    "sgpr_family_has_p": (C.c_int, [C.c_int]),
     "sgpr_potrf_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_trsm_rlt_dev": (C.c_int, [C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
     "sgpr_gemm_nt_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t,
@@ -206,6 +207,11 @@ def dptr(a):
 
 def f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def family_has_p(fam):
+    """family D, or a user kernel that uses the period parameter: hyp = (lx, ly, p, sig)"""
+    return bool(load_library().sgpr_family_has_p(family_id(fam)))
 
 
 def family_id(fam):

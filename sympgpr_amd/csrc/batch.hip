@@ -418,6 +418,7 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
         case SGPR_FAM_A: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_A>, grid, dim3(MT), 0, st, a); break;
         case SGPR_FAM_B: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_B>, grid, dim3(MT), 0, st, a); break;
         case SGPR_FAM_C: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_C>, grid, dim3(MT), 0, st, a); break;
+        case SGPR_FAM_USER: hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_USER>, grid, dim3(MT), 0, st, a); break;
         default:         hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_D>, grid, dim3(MT), 0, st, a); break;
         }
         SGPR_CHECK_LAUNCH();
@@ -452,7 +453,7 @@ int fit_batch(int family, int nbatch, int npts, const double *x, const double *y
         return SGPR_E_ARG;
     }
     if (nbatch == 0) return 0;
-    if (family < SGPR_FAM_A || family > SGPR_FAM_D) { set_error("fit_batch: unknown kernel family"); return SGPR_E_ARG; }
+    if (family < SGPR_FAM_A || family > SGPR_FAM_USER) { set_error("fit_batch: unknown kernel family"); return SGPR_E_ARG; }
     if (n > BMAX) return fit_batch_mid(family, nbatch, npts, n, reg, x, y, z, hyp, nhyp, sig2n, alpha, nll, info);
     const size_t B = (size_t)nbatch;
     const int grid = nbatch < 1024 ? nbatch : 1024;
@@ -488,6 +489,7 @@ int fit_batch(int family, int nbatch, int npts, const double *x, const double *y
     case SGPR_FAM_A: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_A>, dim3(grid), dim3(LT), 0, st, a); break;
     case SGPR_FAM_B: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_B>, dim3(grid), dim3(LT), 0, st, a); break;
     case SGPR_FAM_C: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_C>, dim3(grid), dim3(LT), 0, st, a); break;
+    case SGPR_FAM_USER: hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_USER>, dim3(grid), dim3(LT), 0, st, a); break;
     default:         hipLaunchKernelGGL(fit_batch_kernel<SGPR_FAM_D>, dim3(grid), dim3(LT), 0, st, a); break;
     }
     SGPR_CHECK_LAUNCH();

@@ -355,8 +355,8 @@ static int fit_create_common(int family, int d, int n_pts, const double *X, size
     if (d == 1) {
         if ((rc = make_kconst(family, hyp, nhyp, &f->kc))) { delete f; return rc; }
     } else {
-        const int need = family == SGPR_FAM_D ? 3 * d + 1 : 2 * d + 1;
-        if (d < 1 || d > 3 || nhyp != need || !hyp || family < SGPR_FAM_A || family > SGPR_FAM_D) {
+        const int need = family_has_p(family) ? 3 * d + 1 : 2 * d + 1;
+        if (d < 1 || d > 3 || nhyp != need || !hyp || family < SGPR_FAM_A || family > SGPR_FAM_USER) {
             delete f;
             set_error("fit_create_nd: d in 1..3, hyp = (lq_1..lq_d, lP_1..lP_d, sig) -- (lq.., lP.., p_1..p_d, sig) for family D");
             return SGPR_E_ARG;
@@ -788,7 +788,7 @@ int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, doub
                               hipMemcpyHostToDevice, f->st));
     double hyp1[4] = {f->kc.lx, f->kc.ly, f->kc.sig, 0.0};
     int nh1 = 3;
-    if (f->family == SGPR_FAM_D) { hyp1[2] = f->kc.p; hyp1[3] = f->kc.sig; nh1 = 4; }
+    if (family_has_p(f->family)) { hyp1[2] = f->kc.p; hyp1[3] = f->kc.sig; nh1 = 4; }
     const double *hyp = f->d > 1 ? f->hyp_nd : hyp1;
     if ((rc = predict_nd(f->family, f->d, m, dT.as<double>(), (size_t)m, f->npts, f->dX, (size_t)f->npts, hyp,
                          f->d > 1 ? f->nhyp_nd : nh1,
@@ -883,6 +883,8 @@ int sgpr_gram_nd_sel_dev(int family, int d, int mi, int mj, const double *Xb, si
 
 size_t sgpr_potrf_workspace(int n) { return potrf_workspace(n); }
 size_t sgpr_potrf_inverses_bytes(int n) { return n <= 0 ? 0 : (size_t)((n + LEAF - 1) / LEAF) * LEAF * LEAF * sizeof(double); }
+
+int sgpr_family_has_p(int family) { return family_has_p(family) ? 1 : 0; }
 
 int sgpr_release_device_streams(int device)
 {

@@ -34,6 +34,7 @@ struct KConst {
 };
 enum { DERIV_NONE = 0, DERIV_LX = 1, DERIV_LY = 2 };
 int make_kconst(int family, const double *hyp, int nhyp, KConst *out);
+bool family_has_p(int family);   // the family's hyp holds a period parameter p between the lengths and sig
 int make_kconst_l(int family, const double *l, int nl, KConst *out);  // sig = 1
 
 // ---- gram.hip

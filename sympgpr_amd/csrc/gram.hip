@@ -186,6 +186,7 @@ __global__ void kernel_eval_kernel(int which, int m, const double *xa, const dou
 template <int FAM>
 __device__ double extra_eval(int which, double xa, double ya, double xb, double yb, const KConst &kc)
 {
+    if constexpr (FAM == SGPR_FAM_USER) return gen::extra<SGPR_FAM_USER>(which, xa, ya, xb, yb, kc.lx, kc.ly, kc.p);
     const double lx2 = kc.lx2, ly2 = kc.ly2, dy = ya - yb;
     if constexpr (FAM == SGPR_FAM_A || FAM == SGPR_FAM_D) {
         const double h = FAM == SGPR_FAM_A ? 0.5 * xa - 0.5 * xb : kc.p * (xa - xb);
@@ -418,6 +419,7 @@ int dispatch_family(int family, F &&f)
     case SGPR_FAM_B: return f(std::integral_constant<int, SGPR_FAM_B>());
     case SGPR_FAM_C: return f(std::integral_constant<int, SGPR_FAM_C>());
     case SGPR_FAM_D: return f(std::integral_constant<int, SGPR_FAM_D>());
+    case SGPR_FAM_USER: return f(std::integral_constant<int, SGPR_FAM_USER>());
     }
     set_error("unknown kernel family");
     return SGPR_E_ARG;
@@ -425,17 +427,20 @@ int dispatch_family(int family, F &&f)
 
 }  // namespace
 
+bool family_has_p(int family) { return family == SGPR_FAM_D || (family == SGPR_FAM_USER && gen::user_has_p); }
+
 int make_kconst(int family, const double *hyp, int nhyp, KConst *out)
 {
-    const int need = family == SGPR_FAM_D ? 4 : 3;
-    if (family < 0 || family > 3 || !hyp || nhyp != need) {
+    const bool has_p = family_has_p(family);
+    const int need = has_p ? 4 : 3;
+    if (family < SGPR_FAM_A || family > SGPR_FAM_USER || !hyp || nhyp != need) {
         set_error("hyp must hold (lx, ly, sig) -- (lx, ly, p, sig) for family D");
         return SGPR_E_ARG;
     }
     KConst k{};
     k.lx = hyp[0];
     k.ly = hyp[1];
-    k.p = family == SGPR_FAM_D ? hyp[2] : 0.0;
+    k.p = has_p ? hyp[2] : 0.0;
     k.sig = hyp[nhyp - 1];
     k.lx2 = k.lx * k.lx;
     k.ly2 = k.ly * k.ly;
@@ -459,7 +464,7 @@ int make_kconst(int family, const double *hyp, int nhyp, KConst *out)
 int make_kconst_l(int family, const double *l, int nl, KConst *out)
 {
     double h[4];
-    const int need = family == SGPR_FAM_D ? 3 : 2;
+    const int need = family_has_p(family) ? 3 : 2;
     if (!l || nl != need) {
         set_error("l must hold (lx, ly) -- (lx, ly, p) for family D");
         return SGPR_E_ARG;

@@ -12,6 +12,7 @@
 // 32 d^2 bytes written per pair, so the kernel is even more firmly HBM-write bound than d = 1.
 #include "common.h"
 #include "devmath.h"
+#include "generated/pair_generated.h"
 
 namespace sgpr {
 
@@ -30,7 +31,7 @@ struct NdArgs {
     long roff[6], coff[6];
     long diag_off;
     double noise, sig;
-    double l2[6], inv_l2[6], inv_l4[6];
+    double l[6], l2[6], inv_l2[6], inv_l4[6];
     double hs[6];            // periodic coordinates: sin(hs (x - x')), hs = 1/2 (A, B) or p_m (D)
 };
 
@@ -38,7 +39,13 @@ struct NdArgs {
 template <int FAM, int D, int M>
 __device__ __forceinline__ void coord(const NdArgs &a, double dx, double &arg, double &g, double &nh)
 {
-    if constexpr (FAM != SGPR_FAM_C && M < D / 2) {
+    if constexpr (FAM == SGPR_FAM_USER) {
+        // the user's kernel: its generated factor forms (tools/gen_kernels.py), the q's with hs = p_m when it has one
+        double o[3];
+        if constexpr (M < D / 2) gen::factor<SGPR_FAM_USER, 1>(dx, a.l[M], a.hs[M], o);
+        else                     gen::factor<SGPR_FAM_USER, 0>(dx, a.l[M], 0.0, o);
+        arg = o[0]; g = o[1]; nh = o[2];
+    } else if constexpr (FAM != SGPR_FAM_C && M < D / 2) {
         double s, c;
         sincos_fast(a.hs[M] * dx, s, c);
         const double s2 = s * s, sc = s * c;
@@ -65,10 +72,12 @@ __device__ __forceinline__ void all_coords(const NdArgs &a, const double *xa, co
 
 // E[m]: the factor that multiplies nh[m] on the diagonal blocks -- sig k for the product kernels (one exp
 // per pair), sig f_m for the sum kernel (one exp per coordinate)
+template <int FAM> constexpr bool is_sum() { return FAM == SGPR_FAM_B || (FAM == SGPR_FAM_USER && gen::user_is_sum); }
+
 template <int FAM, int D>
 __device__ __forceinline__ void weights(const NdArgs &a, const double (&arg)[D], double (&E)[D])
 {
-    if constexpr (FAM == SGPR_FAM_B) {
+    if constexpr (is_sum<FAM>()) {
 #pragma unroll
         for (int m = 0; m < D; ++m) E[m] = a.sig * exp_fast(arg[m]);
     } else {
@@ -117,8 +126,8 @@ __global__ __launch_bounds__(NT) void gram_nd_kernel(const NdArgs a)
         for (int ca = 0; ca < D; ++ca) {
 #pragma unroll
             for (int cb = 0; cb < D; ++cb) {
-                const double off0 = (FAM == SGPR_FAM_B) ? 0.0 : -E0[ca] * (g0[ca] * g0[cb]);
-                const double off1 = (FAM == SGPR_FAM_B) ? 0.0 : -E1[ca] * (g1[ca] * g1[cb]);
+                const double off0 = is_sum<FAM>() ? 0.0 : -E0[ca] * (g0[ca] * g0[cb]);
+                const double off1 = is_sum<FAM>() ? 0.0 : -E1[ca] * (g1[ca] * g1[cb]);
                 const double k0 = (ca == cb) ? __builtin_fma(E0[ca], nh0[ca], n0) : off0;
                 const double k1 = (ca == cb) ? __builtin_fma(E1[ca], nh1[ca], n1) : off1;
                 if (a.sel && (a.roff[ca] < 0 || a.coff[cb] < 0)) continue;      // block not wanted by this call
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(NT) void predict_nd_kernel(const NdArgs a, int m, c
         for (int c = 0; c < D; ++c) { al[c] = alpha[(size_t)c * a.mj + j]; S = __builtin_fma(g[c], al[c], S); }
 #pragma unroll
         for (int c = 0; c < D; ++c) {  // sum_b K_cb alpha_b = E (nh_c al_c - g_c (S - g_c al_c)); sum kernel: E_c nh_c al_c
-            const double cross = (FAM == SGPR_FAM_B) ? 0.0 : -g[c] * (S - g[c] * al[c]);
+            const double cross = is_sum<FAM>() ? 0.0 : -g[c] * (S - g[c] * al[c]);
             acc[c] = __builtin_fma(E[c], __builtin_fma(nh[c], al[c], cross), acc[c]);
         }
     }
@@ -177,17 +186,19 @@ __global__ __launch_bounds__(NT) void predict_nd_kernel(const NdArgs a, int m, c
 int fill_args(int family, int d, const double *hyp, int nhyp, NdArgs &a)
 {
     if (d < 1 || d > 3) { set_error("d must be 1, 2 or 3"); return SGPR_E_ARG; }
-    if (family < SGPR_FAM_A || family > SGPR_FAM_D) { set_error("unknown kernel family"); return SGPR_E_ARG; }
-    const int need = family == SGPR_FAM_D ? 3 * d + 1 : 2 * d + 1;
+    if (family < SGPR_FAM_A || family > SGPR_FAM_USER) { set_error("unknown kernel family"); return SGPR_E_ARG; }
+    const bool has_p = family_has_p(family);
+    const int need = has_p ? 3 * d + 1 : 2 * d + 1;
     if (!hyp || nhyp != need) {
         set_error("hyp must hold (lq_1..lq_d, lP_1..lP_d, sig) -- (lq.., lP.., p_1..p_d, sig) for family D");
         return SGPR_E_ARG;
     }
     for (int m = 0; m < 2 * d; ++m) {
+        a.l[m] = hyp[m];
         a.l2[m] = hyp[m] * hyp[m];
         a.inv_l2[m] = 1.0 / a.l2[m];
         a.inv_l4[m] = a.inv_l2[m] * a.inv_l2[m];
-        a.hs[m] = (family == SGPR_FAM_D && m < d) ? hyp[2 * d + m] : 0.5;
+        a.hs[m] = (has_p && m < d) ? hyp[2 * d + m] : 0.5;
     }
     a.sig = hyp[nhyp - 1];
     return 0;
@@ -201,6 +212,7 @@ int dispatch_nd(int family, int d, F &&f)
     SGPR_ND_CASE(SGPR_FAM_C, 1); SGPR_ND_CASE(SGPR_FAM_C, 2); SGPR_ND_CASE(SGPR_FAM_C, 3);
     SGPR_ND_CASE(SGPR_FAM_B, 1); SGPR_ND_CASE(SGPR_FAM_B, 2); SGPR_ND_CASE(SGPR_FAM_B, 3);
     SGPR_ND_CASE(SGPR_FAM_D, 1); SGPR_ND_CASE(SGPR_FAM_D, 2); SGPR_ND_CASE(SGPR_FAM_D, 3);
+    SGPR_ND_CASE(SGPR_FAM_USER, 1); SGPR_ND_CASE(SGPR_FAM_USER, 2); SGPR_ND_CASE(SGPR_FAM_USER, 3);
 #undef SGPR_ND_CASE
     set_error("unsupported (family, d)");
     return SGPR_E_ARG;

@@ -16,6 +16,15 @@ template <int FAM, bool OCML>
 __device__ __forceinline__ void pair_eval(double xa, double ya, double xb, double yb,
                                           const KConst &kc, double &kxx, double &kxy, double &kyy)
 {
+    if constexpr (FAM == SGPR_FAM_USER) {
+        // the user's kernel: generated code only (tools/gen_kernels.py)
+        double o[4];
+        gen::pair<SGPR_FAM_USER>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        kxx = kc.sig * o[1];
+        kyy = kc.sig * o[2];
+        kxy = kc.sig * o[3];
+        return;
+    }
     const double dy = ya - yb;
     const double dy2 = dy * dy;
     if constexpr (FAM == SGPR_FAM_C) {
@@ -65,12 +74,13 @@ template <int FAM, int DL>
 __device__ __forceinline__ void pair_eval_d(double xa, double ya, double xb, double yb,
                                             const KConst &kc, double &dxx, double &dxy, double &dyy)
 {
-    if constexpr (FAM == SGPR_FAM_B) {
+    if constexpr (FAM == SGPR_FAM_B || FAM == SGPR_FAM_USER) {
         // the sum kernel's dl-functions (kernels_sum.f90:133-208) come straight from the generator
-        // (tools/gen_kernels.py): no driver differentiates this family, nothing to hand-optimise
+        // (tools/gen_kernels.py): no driver differentiates this family, nothing to hand-optimise; the user slot has
+        // nothing but generated code
         double o[4];
-        if constexpr (DL == DERIV_LX) gen::pair_dlx<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
-        else                          gen::pair_dly<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        if constexpr (DL == DERIV_LX) gen::pair_dlx<FAM>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        else                          gen::pair_dly<FAM>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
         dxx = kc.sig * o[1];
         dyy = kc.sig * o[2];
         dxy = kc.sig * o[3];
@@ -116,10 +126,10 @@ __device__ __forceinline__ void pair_eval_d(double xa, double ya, double xb, dou
 template <int FAM, int DL>
 __device__ __forceinline__ double kern_eval_d(double xa, double ya, double xb, double yb, const KConst &kc)
 {
-    if constexpr (FAM == SGPR_FAM_B) {
+    if constexpr (FAM == SGPR_FAM_B || FAM == SGPR_FAM_USER) {
         double o[4];
-        if constexpr (DL == DERIV_LX) gen::pair_dlx<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
-        else                          gen::pair_dly<SGPR_FAM_B>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        if constexpr (DL == DERIV_LX) gen::pair_dlx<FAM>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        else                          gen::pair_dly<FAM>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
         return o[0];
     }
     const double dy = ya - yb;
@@ -142,6 +152,11 @@ template <int FAM, bool OCML>
 __device__ __forceinline__ double kern_eval(double xa, double ya, double xb, double yb,
                                             const KConst &kc)
 {
+    if constexpr (FAM == SGPR_FAM_USER) {
+        double o[4];
+        gen::pair<SGPR_FAM_USER>(xa, ya, xb, yb, kc.lx, kc.ly, kc.p, o);
+        return o[0];
+    }
     const double dy = ya - yb;
     if constexpr (FAM == SGPR_FAM_C) {
         const double dx = xa - xb;

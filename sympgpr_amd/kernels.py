@@ -18,9 +18,9 @@ __all__ = ["kern_num", "d2kdxdx0_num", "d2kdydy0_num", "d2kdxdy0_num", "dkdlx_nu
 
 def _eval(which, x_a, y_a, x_b, y_b, lx, ly, p):
     fam = ops.get_family()
-    if fam == "D":
+    if L.family_has_p(fam):
         if p is None:
-            raise TypeError("family D kernels take 7 arguments (x_a, y_a, x_b, y_b, lx, ly, p)")
+            raise TypeError("family %s kernels take 7 arguments (x_a, y_a, x_b, y_b, lx, ly, p)" % fam)
         l = (lx, ly, p)
     else:
         if p is not None:

@@ -16,6 +16,8 @@ stats() {   # stats <tag> <bench args...>: the bench line under rocprofv3 + the 
 if [ "$1" = main ]; then
     timeout -k 10 600 python3 bench.py > $O/bench_n131072.json 2> $O/bench_n131072.err &&
     stats n131072 --cpu-sample 0 &&
+    SGPR_GEMM_KMAX=0 timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > $O/bench_n131072_kmax0.json 2> $O/bench_n131072_kmax0.err &&
+    timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 > $O/bench_n131072_kmax8192.json 2> $O/bench_n131072_kmax8192.err &&
     timeout -k 10 300 python3 bench.py --n-pts 8192 --steps 10 --warmup 3 > $O/bench_n16384.json 2> $O/bench_n16384.err &&
     stats n16384 --n-pts 8192 --steps 2 --warmup 1 --cpu-sample 0 &&
     timeout -k 10 600 python3 bench.py --d 2 --n-pts 32768 --family C --cpu-sample 2048 > $O/bench_henon_d2_n131072.json 2> $O/bench_henon.err &&
@@ -25,6 +27,8 @@ if [ "$1" = main ]; then
     timeout -k 10 300 python3 tools/potrf_modes.py 2048 4096 8192 16384 24576 32768 2>&1 | grep mode > $O/potrf_sizes.txt &&
     timeout -k 10 300 python3 tools/solve_speed.py 4096 8192 16384 32768 65536 2>&1 | grep solve > $O/solve_sizes.txt &&
     cp $O/prof_n131072/p_agent_info.csv $O/agent_info.csv
+elif [ "$1" = batch ]; then
+    timeout -k 10 900 python3 tools/batch_rate.py 2>/dev/null > $O/batch_rate.md
 elif [ "$1" = mfma ]; then
     C="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE"
     timeout -k 10 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_mfma_n131072 -o p -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-launch-events > $O/pmc_mfma_n131072.json 2> $O/pmc_mfma_n131072.err &&
