@@ -143,7 +143,11 @@ def launch_ranks(n):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    # the launcher's own argparse resolves abbreviations before it hands the rest to the script: "--d" is an ambiguous
+    # prefix of its --duplicate-* options, so the children get the long spelling
+    for a in sys.argv[1:]:
+        cmd.append("--pairs-per-point" + a[3:] if (a == "--d" or a.startswith("--d=")) else a)
     return subprocess.call(cmd)
 
 
@@ -154,7 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n-pts", type=int, default=65536, help="training points N (matrix order n = 2*d*N)")
     ap.add_argument("--family", default="A")
-    ap.add_argument("--d", type=int, default=1,
+    ap.add_argument("--d", "--pairs-per-point", dest="d", type=int, default=1,
                     help="canonical pairs per training point (matrix order n = 2*d*N); 1 = the reference's "
                          "(q, P) layout, 2 / 3 = BASELINE configs 03_henon_heiles / 05_tokamak; N = 65536 with "
                          "--d 2 is the n = 262144 multi-GPU configuration")

@@ -116,10 +116,11 @@ def test_user_slot_equals_hand_written_family_c_everywhere(uf):
     hm, hp = [0.9, 0.9, 1.0], [0.9, 0.9, 1.0]
     out = {}
     for fam in ("USER", "C"):
-        with SympFit(fam, q, P, ztrain, hm, 1e-6, lower_only=False) as f:
+        with SympFit(fam, q, P, ztrain, hm, 1e-4, lower_only=False) as f:
             Kyinv = f.run().inverse()
-        with SympFit(fam, q, p, ztrainp, hp, 1e-6, reg=True, lower_only=False) as f:
+        with SympFit(fam, q, p, ztrainp, hp, 1e-4, reg=True, lower_only=False) as f:
             Kyinvp = f.run().inverse()
         out[fam] = run_map(0, 6, 5, hm, np.linspace(-0.5, 0.5, 5), np.linspace(0.4, -0.4, 5), xtrain, ztrain, Kyinv, hp, xtrainp,
                            ztrainp, Kyinvp, family=fam)
-    assert _rel(out["USER"][0], out["C"][0]) < 1e-9 and _rel(out["USER"][1], out["C"][1]) < 1e-9
+    # (150 SE-kernel points on [-1, 1]^2 with l = 0.9: cond(Ky) ~ 1e8 even with this noise; the two slots differ by rounding)
+    assert _rel(out["USER"][0], out["C"][0]) < 1e-8 and _rel(out["USER"][1], out["C"][1]) < 1e-8

@@ -13,6 +13,7 @@ cp $S/potrf_sizes.txt $S/solve_sizes.txt $S/agent_info.csv $D/
 cp $S/flow_devs.txt $D/flow_deviations.txt
 python tools/check_frac.py $D > $D/frac_from_kernel_stats.md
 [ -f $S/batch_rate.md ] && cp $S/batch_rate.md $D/
+for g in $S/rehearsal_one_card_*.json; do [ -f $g ] && grep '^{' $g | tail -1 > $D/$(basename $g); done
 for n in n131072 n16384; do
     [ -f $S/pmc_mfma_busy_$n.txt ] && cp $S/pmc_mfma_busy_$n.txt $D/
 done

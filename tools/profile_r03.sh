@@ -27,6 +27,14 @@ if [ "$1" = main ]; then
     timeout -k 10 300 python3 tools/potrf_modes.py 2048 4096 8192 16384 24576 32768 2>&1 | grep mode > $O/potrf_sizes.txt &&
     timeout -k 10 300 python3 tools/solve_speed.py 4096 8192 16384 32768 65536 2>&1 | grep solve > $O/solve_sizes.txt &&
     cp $O/prof_n131072/p_agent_info.csv $O/agent_info.csv
+elif [ "$1" = rehearsal ]; then
+    # NOT measurements: the N > 1 leg end to end on ONE card (all ranks on cuda:0, collectives over gloo)
+    for g in 2 4; do
+        SGPR_BENCH_ONE_CARD=1 timeout -k 10 400 python3 bench.py --gpus $g --n-pts 16384 --nb 2048 --steps 1 --warmup 1 --cpu-sample 0 > $O/rehearsal_one_card_gpus$g.json 2> $O/rehearsal_one_card_gpus$g.err || exit 1
+    done
+    for g in 3 4; do
+        SGPR_BENCH_ONE_CARD=1 timeout -k 10 400 python3 bench.py --gpus $g --d 2 --family C --n-pts 6144 --nb 1024 --steps 1 --warmup 1 --cpu-sample 0 > $O/rehearsal_one_card_d2_gpus$g.json 2> $O/rehearsal_one_card_d2_gpus$g.err || exit 1
+    done
 elif [ "$1" = batch ]; then
     timeout -k 10 900 python3 tools/batch_rate.py 2>/dev/null > $O/batch_rate.md
 elif [ "$1" = mfma ]; then
