@@ -47,6 +47,11 @@ int sgpr_probe_generated_eval(int family, int which, int m, const double *xa, co
  * tasks).  tests/test_queue_plan.py replays the list on the CPU. */
 int sgpr_probe_queue_plan(int n, int nworkers, int *starts_out, int max_starts, unsigned *tasks_out, int max_tasks,
                           int *counts);
+/* ... with the hand-over point: the queue factors panels 0 .. nq-1 only and leaves the block behind them (all their updates
+ * applied) to the look-ahead driver; nq < 0: the default of this order (SGPR_Q_TAIL).  counts has FOUR entries here:
+ * counts[3] = nq used. */
+int sgpr_probe_queue_plan_partial(int n, int nworkers, int nq, int *starts_out, int max_starts, unsigned *tasks_out,
+                                  int max_tasks, int *counts);
 /* per-task time stamps of the queue factorisations that follow in this process (8 words per ticket: 100 MHz real
  * time at ticket drawn / inputs ready / published, then task word 1 << 32 | task word 0); _end copies them out and
  * switches the recording off again.  (words 4..7: ticket of the next task returned, out of the products, stores drained, write-back through.)  Behind the 8 * max_tasks ticket words: 2 words per worker workgroup (1024: place

@@ -122,6 +122,8 @@ PROBE_SIGNATURES = {
     "sgpr_probe_generated_eval": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, _dp]),
     "sgpr_probe_queue_plan": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint), C.c_int,
                                         C.POINTER(C.c_int)]),
+    "sgpr_probe_queue_plan_partial": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_uint),
+                                                C.c_int, C.POINTER(C.c_int)]),
     "sgpr_probe_queue_trace_begin": (C.c_int, [C.c_int]),
     "sgpr_probe_queue_trace_end": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sgpr_probe_queue_postmortem": (C.c_int, [C.c_int]),

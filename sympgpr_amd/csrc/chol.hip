@@ -743,8 +743,9 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
 struct PanelSeq {
     double *A;              // origin of the block being factored
     size_t lda;
-    int nblk;
-    const int *pstart;      // nblk + 1 panel boundaries (device)
+    int nblk;               // panels this kernel runs: 0 .. nblk-1 (the queue's part of the schedule)
+    int nblk_all;           // panels of the whole schedule (the band of panel nblk-1 is the diagonal block of panel nblk, if any)
+    const int *pstart;      // nblk_all + 1 panel boundaries (device)
     double *inv;            // leaf inverses of the block
     int *dinfo;
     int goff;               // global index of the block's first row (LAPACK info)
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(LT) void panel_seq_kernel(const PanelSeq q)
     __shared__ int sh[2];
     const int g = blockIdx.x;
     for (int k = 0; k < q.nblk; ++k) {
-        const int k0 = q.pstart[k], w = q.pstart[k + 1] - k0, wnext = k + 1 < q.nblk ? q.pstart[k + 2] - q.pstart[k + 1] : 0;
+        const int k0 = q.pstart[k], w = q.pstart[k + 1] - k0, wnext = k + 1 < q.nblk_all ? q.pstart[k + 2] - q.pstart[k + 1] : 0;
         PanelArgs a{};
         a.P = q.A + k0 + (size_t)k0 * q.lda; a.lda = q.lda;
         a.W = w / LEAF;
@@ -981,19 +982,41 @@ namespace {
 // loses 6 % of the chip and the tile map its 256-CU geometry).
 // The numbers are the same operations in a different order; the leaf workspace layout is shared with
 // the recursive driver, so the solves do not care which one produced L.
-// events of one look-ahead factorisation; destroyed on every exit path
+// Events of one factorisation, BORROWED from a pool the calling thread keeps per device and never gives back.
+// Creating and destroying them per call (rounds 1-2) put runtime housekeeping -- event / signal memory being released while
+// the device is still running the factorisation that used it -- beside kernels whose workgroups wait for each other; see
+// DESIGN 3.9 for what that did to the task-queue driver.  Re-recording an event later is safe: a stream's wait refers to
+// the record that was current when the wait was enqueued.  Nested sets (the queue driver, then the look-ahead driver for
+// the block it leaves) take consecutive slices of the pool.
+struct EventPool {
+    std::vector<hipEvent_t> ev;
+    size_t top = 0;
+};
+thread_local EventPool t_event_pool[64];
+
 struct EventSet {
     std::vector<hipEvent_t> ev;
+    EventPool *pool = nullptr;
+    size_t base = 0;
     int create(size_t count)
     {
-        ev.assign(count, nullptr);
-        for (auto &e : ev) SGPR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        int dev = 0;
+        SGPR_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) { set_error("potrf: device index out of range"); return SGPR_E_ARG; }
+        pool = &t_event_pool[dev];
+        base = pool->top;
+        while (pool->ev.size() < base + count) {
+            hipEvent_t e = nullptr;
+            SGPR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            pool->ev.push_back(e);
+        }
+        pool->top = base + count;
+        ev.assign(pool->ev.begin() + (long)base, pool->ev.begin() + (long)(base + count));
         return 0;
     }
     ~EventSet()
     {
-        for (auto &e : ev)
-            if (e) (void)hipEventDestroy(e);
+        if (pool) pool->top = base;
     }
 };
 // whatever happens in between, the caller's stream waits for everything queued on the side stream
@@ -1137,7 +1160,7 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         StreamJoin join_p{sp, su, es.ev[1]};                    // ... and leave it again on every exit path
         StreamJoin join_w{sw, su, es.ev[2]};
         PanelSeq ps{};
-        ps.A = A; ps.lda = lda; ps.nblk = plan->nblk; ps.pstart = ws.pstart;
+        ps.A = A; ps.lda = lda; ps.nblk = plan->nq; ps.nblk_all = plan->nblk; ps.pstart = ws.pstart;
         ps.inv = inv_blk; ps.dinfo = c.dinfo; ps.goff = off0; ps.flags = flags_blk;
         ps.ver = ws.ver; ps.ver_ld = tn; ps.tver = ws.tver; ps.abort = cholq::abort_word(ws);
         ps.census = cholq::trace_panel_base((int)(plan->tasks.size() / 2));
@@ -1152,6 +1175,18 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     if (qdebug) {
         SGPR_HIP(hipStreamSynchronize(su));
         cholq::postmortem(false);
+    }
+    if (plan->nq < plan->nblk) {
+        // the block the queue left (every update of its panels applied, its rows of L final): the look-ahead driver
+        const int S = plan->starts[plan->nq];
+        Ctx ct = c;
+        ct.qws = nullptr;
+        // The host WAITS here.  With the look-ahead driver's ~100 launches enqueued behind the persistent kernels (on this
+        // stream and on the high-priority side stream, all of them blocked by the joins above) the stall of DESIGN 3.9 was no
+        // longer rare but came in the first factorisation, every time, ~4 ms in; with nothing enqueued behind them 400 in a
+        // row were clean (and 1 in ~300 - 1700 still stalls, as with the whole factorisation in the queue).
+        SGPR_HIP(hipStreamSynchronize(su));
+        return potrf_lookahead(n - S, A + S + (size_t)S * lda, lda, ct, 0, off0 + S);
     }
     return 0;
 }

@@ -38,6 +38,8 @@ constexpr int MAX_ORDER = 131072;          // 9-bit panel index at >= 256 column
 
 struct Plan {
     int n = 0, nblk = 0, wmax = 0, nworkers = 0;
+    int nq = 0;                            // panels 0 .. nq-1 are factored by the queue; the block that is left (order n - starts[nq],
+                                           // every update of the first nq panels applied) goes to the look-ahead driver
     std::vector<int> starts;               // nblk + 1 panel boundaries (multiples of 256)
     std::vector<unsigned> tasks;           // two words per task, in ticket order: every input of a task comes from a smaller ticket
     double flop = 0.0;                     // algorithmic flop of the tasks (2k per updated element on / below the diagonal)
@@ -48,7 +50,13 @@ struct Plan {
 // panel boundaries of the default schedule for order n (SGPR_Q_* override)
 std::vector<int> default_starts(int n);
 // host only: the ordered task list for given panel boundaries (all multiples of 256, starts[0] = 0, back() = n)
-int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out);
+// nq < 0: all panels
+int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out, int nq = -1);
+// the hand-over point of the schedule: with SGPR_Q_TAIL=<rows> (default 0: the queue runs everything) the queue runs the
+// panels while more than that many rows are left and the look-ahead driver factors the rest.  Measured: no gain
+// (n = 16384: 30.6 - 31.6 ms against 30.0 for the whole factorisation in the queue and 32.2 for the look-ahead driver), and
+// the host has to wait between the two parts.
+int default_nq(int n, const std::vector<int> &starts);
 // cached per (n, nworkers); nullptr on failure (error text set)
 const Plan *get_plan(int n, int nworkers);
 

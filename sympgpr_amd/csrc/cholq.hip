@@ -116,7 +116,16 @@ struct Cand {
 
 }  // namespace
 
-int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out)
+int default_nq(int n, const std::vector<int> &starts)
+{
+    static const int tail = std::max(0, env_int("SGPR_Q_TAIL", 0));
+    const int nblk = (int)starts.size() - 1;
+    int nq = nblk;
+    while (nq > 1 && n - starts[nq - 1] <= tail) --nq;      // panel nq - 1 still has more than `tail` rows under and beside it
+    return tail == 0 ? nblk : nq;
+}
+
+int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out, int nq)
 {
     if (n <= 0 || n % TM != 0 || n > MAX_ORDER || starts.size() < 2 || starts.front() != 0 || starts.back() != n) {
         set_error("cholq: bad plan request");
@@ -128,6 +137,9 @@ int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out)
         if (w <= 0 || w % TM != 0 || w > 2048) { set_error("cholq: panel widths must be multiples of 256, at most 2048"); return SGPR_E_ARG; }
     }
     if (nblk > 511) { set_error("cholq: too many panels"); return SGPR_E_ARG; }
+    if (nq < 0 || nq > nblk) nq = nblk;
+    if (nq < 1) { set_error("cholq: the queue needs at least one panel"); return SGPR_E_ARG; }
+    const int S = starts[nq];          // the queue's part: columns [0, S)
     Model M;
     M.kcap = std::max(1, std::min(16, env_int("SGPR_Q_KCAP", 16)));
     M.leaf = env_int("SGPR_Q_LEAF_US", (int)M.leaf);
@@ -135,18 +147,18 @@ int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out)
     M.fixed = env_int("SGPR_Q_FIXED_US", (int)M.fixed);
     M.band0 = env_int("SGPR_Q_BAND0_US", (int)M.band0);
     out = Plan();
-    out.n = n; out.nblk = nblk; out.starts = starts; out.nworkers = nworkers;
+    out.n = n; out.nblk = nblk; out.starts = starts; out.nworkers = nworkers; out.nq = nq;
     for (int k = 0; k < nblk; ++k) out.wmax = std::max(out.wmax, starts[k + 1] - starts[k]);
     const int tm = n / TM, tn = n / TN;
     auto lower = [](int i, int j) { return TM * i + TM - 1 >= TN * j; };
     std::vector<int> pcol((size_t)tn), cap((size_t)tn);          // panel of column tile j; leaf columns it must have taken before its panel
     for (int k = 0; k < nblk; ++k)
-        for (int j = starts[k] / TN; j < starts[k + 1] / TN; ++j) { pcol[j] = k; cap[j] = starts[k] / LEAF; }
+        for (int j = starts[k] / TN; j < starts[k + 1] / TN; ++j) { pcol[j] = k; cap[j] = std::min(starts[k], S) / LEAF; }
     std::vector<int> ver((size_t)tm * tn, 0), rowfin((size_t)tn, 0);
     std::vector<char> busy((size_t)tm * tn, 0), inheap((size_t)tm * tn, 0);
     std::vector<char> tstate((size_t)nblk * tm, 3);              // 0 pending, 1 in heap, 2 issued, 3 none
     std::vector<int> tleft((size_t)nblk, 0);
-    for (int k = 0; k < nblk; ++k)
+    for (int k = 0; k < nq; ++k)
         for (int i = (k + 2 <= nblk ? starts[k + 2] / TM : tm); i < tm; ++i) { tstate[(size_t)k * tm + i] = 0; ++tleft[k]; }
     std::vector<char> chain_done((size_t)nblk, 0), band_done((size_t)nblk, 0);
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;
@@ -186,7 +198,7 @@ int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out)
         return true;
     };
     auto try_chain = [&]() {
-        if (chain_running || next_chain >= nblk) return;
+        if (chain_running || next_chain >= nq) return;
         const int k = next_chain, need = starts[k] / LEAF, j0 = starts[k] / TN, W = (starts[k + 1] - starts[k]) / LEAF;
         for (int g = 0; g < W; ++g) {
             const int vi = starts[k] / TM + (g >> 1);
@@ -286,8 +298,8 @@ int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out)
         }
     }
     // everything done?  (a planner bug would show here, never on the device)
-    bool complete = next_chain == nblk && !chain_running;
-    for (int k = 0; k < nblk && complete; ++k) complete = chain_done[k] && tleft[k] == 0 && (k + 1 >= nblk || band_done[k]);
+    bool complete = next_chain == nq && !chain_running;
+    for (int k = 0; k < nq && complete; ++k) complete = chain_done[k] && tleft[k] == 0 && (k + 1 >= nblk || band_done[k]);
     for (int i = 0; i < tm && complete; ++i)
         for (int j = 0; j < tn && complete; ++j)
             if (lower(i, j) && ver[(size_t)i * tn + j] < cap[j]) complete = false;
@@ -304,7 +316,8 @@ const Plan *get_plan(int n, int nworkers)
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
     Plan *p = new Plan();
-    if (build_plan(n, default_starts(n), nworkers, *p) || p->tasks.size() / 2 > max_tasks(n)) { delete p; g_plans[key] = nullptr; return nullptr; }
+    const std::vector<int> st = default_starts(n);
+    if (build_plan(n, st, nworkers, *p, default_nq(n, st)) || p->tasks.size() / 2 > max_tasks(n)) { delete p; g_plans[key] = nullptr; return nullptr; }
     // page-locked image for the asynchronous upload: [starts | tasks]
     const size_t words = (size_t)(p->nblk + 1) + p->tasks.size();
     void *pin = nullptr;

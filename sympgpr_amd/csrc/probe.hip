@@ -354,6 +354,23 @@ extern "C" int sgpr_probe_queue_plan(int n, int nworkers, int *starts_out, int m
     return 0;
 }
 
+// the same with the hand-over point chosen: nq panels for the queue (< 0: the default of this order); counts[3] = nq used
+extern "C" int sgpr_probe_queue_plan_partial(int n, int nworkers, int nq, int *starts_out, int max_starts, unsigned *tasks_out,
+                                             int max_tasks, int *counts)
+{
+    cholq::Plan p;
+    const std::vector<int> st = cholq::default_starts(n);
+    const int rc = cholq::build_plan(n, st, nworkers, p, nq < 0 ? cholq::default_nq(n, st) : nq);
+    if (rc) return rc;
+    counts[0] = p.nblk;
+    counts[1] = (int)(p.tasks.size() / 2);
+    counts[2] = (int)p.model_us;
+    counts[3] = p.nq;
+    for (int k = 0; k <= p.nblk && k < max_starts; ++k) starts_out[k] = p.starts[k];
+    for (size_t t = 0; t < p.tasks.size() && (int)(t / 2) < max_tasks; ++t) tasks_out[t] = p.tasks[t];
+    return 0;
+}
+
 static unsigned long long *g_qtrace = nullptr;
 static int g_qtrace_cap = 0;
 extern "C" int sgpr_probe_queue_trace_begin(int max_tasks)

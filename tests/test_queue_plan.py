@@ -47,3 +47,28 @@ def test_plan_model_replay_matches_the_planner():
     starts, tasks, model_us = qs.fetch_plan(n, workers)
     end, busy, wait = qs.simulate(n, starts, tasks, workers)
     assert abs(end - model_us) <= 0.02 * model_us + 5.0
+
+
+@pytest.mark.parametrize("n,workers,nq", [(2048, 248, 1), (2560, 31, 3), (4096, 248, 4), (6144, 240, 11), (16384, 248, -1)])
+def test_partial_plan_hands_over_a_fully_updated_block(n, workers, nq):
+    """the queue factors the first nq panels only (SGPR_Q_TAIL; by default it runs them all): every tile of the
+    block it leaves carries all updates of those panels, every row strip below them is solved, no task touches a later panel"""
+    starts, tasks, model_us, used = qs.fetch_plan_partial(n, workers, nq)
+    assert used == (nq if nq > 0 else used) and 1 <= used <= len(starts) - 1
+    if nq < 0:
+        assert used == len(starts) - 1          # the default hand-over point: none (SGPR_Q_TAIL=0), the queue runs every panel
+    assert qs.check_order(n, starts, tasks, used) == len(tasks)
+    for t in tasks:
+        typ, k, i, j, a, b = qs.unpack(t)
+        assert (k < used) if typ == qs.TASK_T else (128 * b <= starts[used])
+
+
+@pytest.mark.parametrize("n,workers,nq", [(1536, 8, 1), (2560, 248, 2), (2560, 8, 4)])
+def test_partial_plan_replay_then_dense_tail_is_the_cholesky_factor(n, workers, nq):
+    starts, tasks, _, used = qs.fetch_plan_partial(n, workers, nq)
+    rng = np.random.default_rng(n + nq)
+    B = rng.standard_normal((n, n))
+    A = B @ B.T / n + np.eye(n)
+    L = qs.replay(A, starts, tasks, used)
+    Lr = np.linalg.cholesky(A)
+    assert np.abs(L - Lr).max() <= 1e-13 * np.abs(Lr).max()

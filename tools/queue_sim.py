@@ -16,7 +16,7 @@ TASK_U, TASK_T = 0, 1
 
 
 def fetch_plan(n, nworkers):
-    """-> (starts, tasks[ntasks, 2] uint32, the planner's own time estimate in us)"""
+    """-> (starts, tasks[ntasks, 2] uint32, the planner's own time estimate in us): the whole factorisation in the queue"""
     from sympgpr_amd import _lib as L
     probe = L.load_probe_library()
     counts = (C.c_int * 3)()
@@ -27,6 +27,22 @@ def fetch_plan(n, nworkers):
     L.check(probe.sgpr_probe_queue_plan(n, nworkers, starts, nblk + 1, tasks, ntasks, counts), "sgpr_probe_queue_plan")
     t = np.frombuffer(tasks, dtype=np.uint32, count=2 * ntasks).reshape(-1, 2).copy()
     return list(starts), t, float(counts[2])
+
+
+def fetch_plan_partial(n, nworkers, nq=-1):
+    """-> (starts, tasks, model us, nq): the queue factors panels 0 .. nq-1 and hands the rest to the look-ahead driver
+    (nq < 0: the default hand-over point of this order)"""
+    from sympgpr_amd import _lib as L
+    probe = L.load_probe_library()
+    counts = (C.c_int * 4)()
+    L.check(probe.sgpr_probe_queue_plan_partial(n, nworkers, nq, None, 0, None, 0, counts), "sgpr_probe_queue_plan_partial")
+    nblk, ntasks = counts[0], counts[1]
+    starts = (C.c_int * (nblk + 1))()
+    tasks = (C.c_uint * max(2 * ntasks, 2))()
+    L.check(probe.sgpr_probe_queue_plan_partial(n, nworkers, nq, starts, nblk + 1, tasks, ntasks, counts),
+            "sgpr_probe_queue_plan_partial")
+    t = np.frombuffer(tasks, dtype=np.uint32, count=2 * ntasks).reshape(-1, 2).copy()
+    return list(starts), t, float(counts[2]), int(counts[3])
 
 
 def unpack(t):
@@ -41,12 +57,16 @@ def chain_tiles(k, starts):
     return sorted({(starts[k] // TM + g // 2, j0 + c) for g in range(W) for c in range(g + 1)})
 
 
-def check_order(n, starts, tasks):
+def check_order(n, starts, tasks, nq=None):
     """Every input of a task is produced by a task with a smaller ticket, or by a panel kernel whose own inputs
     are; every tile ends up with all its columns applied, every row strip solved against every panel left of it.
-    The panel kernels are run as late as possible here: a task that needs one gets it only if ITS inputs are there."""
+    The panel kernels are run as late as possible here: a task that needs one gets it only if ITS inputs are there.
+    nq: the queue factors panels 0 .. nq-1 only; what is checked then is the state it hands over -- every tile of the
+    block that is left carries all updates of those panels, every row strip below them is solved against all of them."""
     tm, tn = n // TM, n // TN
     nblk = len(starts) - 1
+    nq = nblk if nq is None else nq
+    S = starts[nq]
     ver = np.zeros((tm, tn), dtype=np.int64)
     tver = np.zeros(tn, dtype=np.int64)
     chain_done = set()
@@ -54,6 +74,7 @@ def check_order(n, starts, tasks):
     def run_chain(k):
         """panel kernel k: diagonal strips, and the rows of the next diagonal block (all their tiles there first)"""
         assert k == 0 or (k - 1) in chain_done, ("chain order", k)
+        assert k < nq, ("a panel beyond the queue's part", k)
         need = starts[k] // LEAF
         for (vi, vj) in chain_tiles(k, starts):
             assert ver[vi, vj] >= need, ("chain", k, vi, vj, ver[vi, vj])
@@ -86,7 +107,7 @@ def check_order(n, starts, tasks):
             assert ver[i, j] == a, ("ver", (i, j, a, b), ver[i, j])
             for r in (2 * i, 2 * i + 1, j):
                 need_tver(r, b)
-            capj = max(s for s in starts if s <= 128 * j) // LEAF
+            capj = min(max(s for s in starts if s <= 128 * j), S) // LEAF
             assert b <= capj
             ver[i, j] = b
         else:
@@ -98,32 +119,35 @@ def check_order(n, starts, tasks):
                 assert ver[i, j0 + c] >= base, ("solve", k, i, c)
             assert tver[2 * i] == base and tver[2 * i + 1] == base, ("solve order", k, i, tver[2 * i])
             tver[2 * i] = tver[2 * i + 1] = starts[k + 1] // LEAF
-    need_chain(nblk - 1)
+    need_chain(nq - 1)
     for i in range(tm):
         for j in range(tn):
             if 256 * i + 255 >= 128 * j:
-                capj = max(s for s in starts if s <= 128 * j) // LEAF
+                capj = min(max(s for s in starts if s <= 128 * j), S) // LEAF
                 assert ver[i, j] == capj, (i, j, ver[i, j], capj)
-    for k in range(nblk - 1):
+    for k in range(min(nq, nblk - 1)):
         for r in range(starts[k + 1] // LEAF, tn):
             assert tver[r] >= starts[k + 1] // LEAF
     return len(tasks)
 
 
-def replay(A, starts, tasks):
+def replay(A, starts, tasks, nq=None):
     """Run the list in ticket order on a dense SPD matrix (lower triangle significant); a panel kernel (diagonal
-    block + the rows of the next one) runs as soon as its inputs are complete.  Returns L (lower)."""
+    block + the rows of the next one) runs as soon as its inputs are complete.  Returns L (lower).
+    nq: the queue's part ends behind panel nq - 1; the block that is left is then factored in one piece (the look-ahead
+    driver's job on the device)."""
     import scipy.linalg
     A = np.array(A, dtype=np.float64, order="F")
     n = A.shape[0]
     tm, tn = n // TM, n // TN
     nblk = len(starts) - 1
+    nq = nblk if nq is None else nq
     ver = np.zeros((tm, tn), dtype=np.int64)
     done = []
 
     def chains():
         k = len(done)
-        while k < nblk:
+        while k < nq:
             need = starts[k] // LEAF
             tiles = set(chain_tiles(k, starts))
             if k + 1 < nblk:
@@ -153,7 +177,11 @@ def replay(A, starts, tasks):
             A[r, c] -= A[r, kk] @ A[c, kk].T
             ver[i, j] = b
         chains()
-    assert len(done) == nblk
+    assert len(done) == nq
+    if nq < nblk:
+        S = starts[nq]
+        D = np.tril(A[S:, S:])
+        A[S:, S:] = np.linalg.cholesky(D + np.tril(D, -1).T)
     return np.tril(A)
 
 
