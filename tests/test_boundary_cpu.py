@@ -219,3 +219,14 @@ def test_family_selection_is_per_thread():
     assert seen == {"fresh": "A", "after": "C"}
     with pytest.raises(ValueError):
         func.set_family("Z")
+
+
+def test_family_table_and_period_parameter():
+    """the five family ids of include/sympgpr_hip.h and which of them carry a period p in hyp (no GPU needed)"""
+    from sympgpr_amd import _lib as L
+    assert L.FAMILIES == {"A": 0, "B": 1, "C": 2, "D": 3, "USER": 4}
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sympgpr_hip.h")).read()
+    for name, val in L.FAMILIES.items():
+        assert re.search(r"SGPR_FAM_%s\s*=\s*%d\b" % (name, val), hdr), name
+    assert L.family_has_p("D") and not any(L.family_has_p(f) for f in "ABC")
+    assert L.family_has_p("USER") in (False, True)

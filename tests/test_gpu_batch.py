@@ -223,3 +223,24 @@ def test_fit_batch_mid_population_and_failures(oracle):
         a_o, nll_o, _ = oracle.fit("A", X[b], Y[b], Z[b], H[b], 1e-2, threads=4)
         assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < 1e-9
         assert nll[b] == pytest.approx(nll_o, rel=1e-10)
+
+
+def test_fit_batch_mid_more_problems_than_one_chunk(oracle):
+    """200 problems of order 2048 = 6.7 GB of images: more than the 6 GiB one chunk of the mid-size path holds, so the batch
+    runs in two passes over the same scratch; problems on both sides of the chunk boundary against the oracle"""
+    from sympgpr_amd.fit import fit_batch
+    rng = np.random.default_rng(2048)
+    B, n_pts = 200, 1024
+    x, y = rng.uniform(0, 2 * np.pi, (B, n_pts)), rng.uniform(-3, 3, (B, n_pts))
+    z = rng.standard_normal((B, 2 * n_pts))
+    l = 2.0 * np.sqrt(12 * np.pi / n_pts)
+    hyp = np.column_stack((l * rng.uniform(0.8, 1.25, B), l * rng.uniform(0.8, 1.25, B), rng.uniform(0.7, 1.4, B)))
+    s2 = rng.uniform(2e-3, 1e-2, B)
+    al, nll, info = fit_batch("A", x, y, z, hyp, s2)
+    assert np.all(info == 0) and np.all(np.isfinite(nll))
+    chunk = (6 << 30) // (2048 * 2048 * 8)
+    assert 0 < chunk < B
+    for b in (0, chunk - 1, chunk, B - 1):
+        a_o, nll_o, _ = oracle.fit("A", x[b], y[b], z[b], hyp[b], s2[b], threads=4)
+        assert np.linalg.norm(al[b] - a_o) / np.linalg.norm(a_o) < 1e-9, b
+        assert nll[b] == pytest.approx(nll_o, rel=1e-10)
