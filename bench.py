@@ -104,7 +104,7 @@ def kernel_code_hash():
     import hashlib
     h = hashlib.sha1()
     for f in ("common.h", "devmath.h", "pair_eval.h", os.path.join("generated", "pair_generated.h"), "leaf.h", "gemm_f64.hip",
-              "gemm_tile.h", "chol.hip", "cholq.hip", "cholq.h", "trsv.hip", "gram.hip", "gram_nd.hip"):
+              "gemm_tile.h", "chol.hip", "cholq.hip", "cholq.h", "trsv.hip", "gram.hip", "gram_nd.hip", "blas_small.hip", "capi.hip"):
         with open(os.path.join(ROOT, "sympgpr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]

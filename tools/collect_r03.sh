@@ -13,6 +13,8 @@ cp $S/potrf_sizes.txt $S/solve_sizes.txt $S/agent_info.csv $D/
 cp $S/flow_devs.txt $D/flow_deviations.txt
 python tools/check_frac.py $D > $D/frac_from_kernel_stats.md
 [ -f $S/batch_rate.md ] && cp $S/batch_rate.md $D/
+for f in launches_n131072.json pmc_fetch_write_summary_n131072.txt pmc_traffic_n131072.json; do [ -f $S/$f ] && cp $S/$f $D/; done
+[ -f $S/gemm_launches_n131072.txt ] && grep -v amdgpu.ids $S/gemm_launches_n131072.txt > $D/gemm_launches_n131072.txt
 for g in $S/rehearsal_one_card_*.json; do [ -f $g ] && grep '^{' $g | tail -1 > $D/$(basename $g); done
 for n in n131072 n16384; do
     [ -f $S/pmc_mfma_busy_$n.txt ] && cp $S/pmc_mfma_busy_$n.txt $D/

@@ -43,6 +43,14 @@ elif [ "$1" = mfma ]; then
     python3 tools/pmc_mfma_busy.py $O/pmc_mfma_n131072/p_counter_collection.csv > $O/pmc_mfma_busy_n131072.txt &&
     timeout -k 10 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_mfma_n16384 -o p -- python3 bench.py --n-pts 8192 --steps 1 --warmup 0 --cpu-sample 0 --no-launch-events > $O/pmc_mfma_n16384.json 2> $O/pmc_mfma_n16384.err &&
     python3 tools/pmc_mfma_busy.py $O/pmc_mfma_n16384/p_counter_collection.csv > $O/pmc_mfma_busy_n16384.txt
+elif [ "$1" = pmc ]; then
+    # HBM traffic of the headline configuration: separate --pmc FETCH_SIZE / WRITE_SIZE passes (counters in their own runs)
+    timeout -k 10 300 python3 tools/gemm_launches.py 65536 --json $O/launches_n131072.json > $O/gemm_launches_n131072.txt 2>&1 || exit 1
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o p -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-launch-events > $O/pmc_$c.json 2> $O/pmc_$c.err || exit 1
+    done
+    python3 tools/pmc_sum.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv > $O/pmc_fetch_write_summary_n131072.txt &&
+    python3 tools/pmc_traffic_json.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv $O/launches_n131072.json 65536 > $O/pmc_traffic_n131072.json
 elif [ "$1" = kmax ]; then
     : > $O/kmax.txt
     for km in 0 8192 16384; do
