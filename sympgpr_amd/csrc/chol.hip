@@ -1140,7 +1140,10 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     if (R > 4) return 1;
     hipStream_t sw = nullptr, sp = nullptr;
     if (queue_streams(qd, dev, R, &sw, &sp)) return 1;
-    const int nworkers = qd.ncu - 8 * R;
+    // SGPR_Q_SLACK=<CUs of the worker set left empty> (default 0).  32 = one per shader engine: with that much room the
+    // workgroups of a preempted-and-restored grid all find a CU again (the stall) -- at 13 % of the throughput.
+    static const int qslack = [] { const char *e = getenv("SGPR_Q_SLACK"); return e ? atoi(e) : 0; }();
+    const int nworkers = qd.ncu - 8 * R - std::max(0, std::min(qslack, 64));
     const cholq::Plan *plan = cholq::get_plan(n, nworkers);
     if (!plan) return 1;
     const cholq::Ws ws = cholq::carve(c.qws, n);

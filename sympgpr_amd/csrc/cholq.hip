@@ -32,9 +32,11 @@ int env_int(const char *name, int dflt)
 int q_min() { static const int v = env_int("SGPR_Q_MIN", 11264); return v; }
 int q_max() { static const int v = std::min(env_int("SGPR_Q_MAX", 28672), MAX_ORDER); return v; }
 // OFF unless SGPR_POTRF_Q=1: 7 - 10 % faster than the look-ahead driver for orders 12288 .. 28672 (n = 16384: 29.1 vs
-// 32.4 ms), but once in a few hundred to a thousand factorisations a handful of workgroups hang in their first operand
-// loads until every other workgroup of the grid has left (tools/queue_stress.py) -- the bounded
-// wait turns that into SGPR_E_HIP after 20 s, never into a wrong factor, and that is not good enough for a default.
+// 32.4 ms), but once in a few hundred to a thousand factorisations a handful of workgroups stand still until every other
+// workgroup of the grid has left (tools/queue_stress.py).  DESIGN.md section 3.9: the platform switches queues out and in
+// when the set of active queues changes, and a grid that fills every CU exactly does not always fit back; with one spare
+// CU per shader engine (SGPR_Q_SLACK=32) 6000 of 6000 were clean -- at the look-ahead driver's speed.  The bounded wait
+// turns a stall into SGPR_E_HIP after 20 s, never into a wrong factor, and that is not good enough for a default.
 bool q_on() { static const int v = env_int("SGPR_POTRF_Q", 0); return v != 0; }
 
 size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
