@@ -650,6 +650,9 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
                   a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr,
                   a.flags + E0 + g, g > 0);
         panel_publish(a.flags + 2 + g);
+        // task-queue driver: "something moved" (the workers drain their kernel instance when nothing does, cholq.h)
+        if (a.abort && tid == 0)
+            __hip_atomic_fetch_add((gint *)(a.abort + (cholq::Q_PROG - cholq::Q_ABORT)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg) a.dbg[16 * g + 5] = __builtin_amdgcn_s_memrealtime();
         if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
         return true;
@@ -703,6 +706,8 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
         }
     }
     if (a.tver && r_first < R) panel_publish_val(a.tver + (size_t)(a.tver_r0 + r_first) * cholq::VS, a.tver_val);
+    if (a.abort && tid == 0)
+        __hip_atomic_fetch_add((gint *)(a.abort + (cholq::Q_PROG - cholq::Q_ABORT)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
     return true;
 }
@@ -1188,7 +1193,8 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         // stream and on the high-priority side stream, all of them blocked by the joins above) the stall of DESIGN 3.9 was no
         // longer rare but came in the first factorisation, every time, ~4 ms in; with nothing enqueued behind them 400 in a
         // row were clean (and 1 in ~300 - 1700 still stalls, as with the whole factorisation in the queue).
-        SGPR_HIP(hipStreamSynchronize(su));
+        static const bool nosync = getenv("SGPR_Q_NOSYNC") != nullptr;    // tests of the drain-and-relaunch recovery only
+        if (!nosync) SGPR_HIP(hipStreamSynchronize(su));
         return potrf_lookahead(n - S, A + S + (size_t)S * lda, lda, ct, 0, off0 + S);
     }
     return 0;

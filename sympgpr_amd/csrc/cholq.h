@@ -69,12 +69,19 @@ bool eligible(int n);
 // waiting workgroup.  On one cache line the readers starved the atomics: once in a few hundred factorisations a few
 // workgroups stood for as long as everybody else waited -- for them (tools/queue_stress.py).  So: a line of its own.
 constexpr int Q_ABORT = 32;
+// Third and fourth line of the state words.  Q_PROG: bumped at every publish (workers and panel strips) -- "something moved".
+// Q_DRAIN: set by a worker that has seen nothing move for Q_GIVEUP_TICKS; every worker that is NOT inside a task's
+// products then leaves (its ticket is simply not done), the ones that are finish their task and leave, the kernel instance
+// ends, and the next instance (already enqueued behind a rewind of the ticket head) carries on.  Why: DESIGN 3.9 -- when the
+// platform has switched the queues out and in, a few workgroups may not get their CU back until somebody else leaves one.
+constexpr int Q_PROG = 64, Q_DRAIN = 96, Q_WORDS = 128;
+constexpr int Q_INSTANCES = 6;             // worker kernel instances enqueued per factorisation at least (+1 per ~8 ms of plan; all but the first normally find nothing to do)
 // ... and every version word too: VS ints apart = one 128-byte line per word.  Packed, the 128 words that say how far
 // each row strip is solved sat on four lines that every waiting workgroup of the chip polled.
 constexpr size_t VS = 32;                // qs[32..63]: give-up word + the panel kernel's post-mortem words
 
 struct Ws {                                // pointers into the queue's part of the workspace
-    int *qs;                               // 64 ints: [0] ticket head, [2..7] post-mortem of the worker that gave up, [Q_ABORT] give-up word
+    int *qs;                               // Q_WORDS ints: [0] ticket head, [2..7] post-mortem of the worker that gave up, [Q_ABORT] give-up word, [Q_PROG], [Q_DRAIN]
     int *ver;                              // tm x tn words (VS ints apart): leading 128-column blocks of L applied to tile (i, j)
     int *tver;                             // tn words (VS ints apart): leading blocks final per 128-row strip
     int *pstart;                           // nblk + 1

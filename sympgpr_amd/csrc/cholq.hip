@@ -29,15 +29,13 @@ int env_int(const char *name, int dflt)
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;
 }
-int q_min() { static const int v = env_int("SGPR_Q_MIN", 11264); return v; }
+int q_min() { static const int v = env_int("SGPR_Q_MIN", 13312); return v; }
 int q_max() { static const int v = std::min(env_int("SGPR_Q_MAX", 28672), MAX_ORDER); return v; }
-// OFF unless SGPR_POTRF_Q=1: 7 - 10 % faster than the look-ahead driver for orders 12288 .. 28672 (n = 16384: 29.1 vs
-// 32.4 ms), but once in a few hundred to a thousand factorisations a handful of workgroups stand still until every other
-// workgroup of the grid has left (tools/queue_stress.py).  DESIGN.md section 3.9: the platform switches queues out and in
-// when the set of active queues changes, and a grid that fills every CU exactly does not always fit back; with one spare
-// CU per shader engine (SGPR_Q_SLACK=32) 6000 of 6000 were clean -- at the look-ahead driver's speed.  The bounded wait
-// turns a stall into SGPR_E_HIP after 20 s, never into a wrong factor, and that is not good enough for a default.
-bool q_on() { static const int v = env_int("SGPR_POTRF_Q", 0); return v != 0; }
+// ON by default (SGPR_POTRF_Q=0 switches it off) for SGPR_Q_MIN <= n <= SGPR_Q_MAX, where it beats the look-ahead driver by
+// 2 - 6 % (n = 16384: 30.2 vs 32.2 ms; below 13312 and above 28672 it does not).  A persistent grid that fills every CU can
+// lose workgroups for a while when the platform switches the queues out and in; the workers notice
+// (nothing published anywhere for 3 ms), drain their kernel instance and the next instance carries on (Q_INSTANCES).
+bool q_on() { static const int v = env_int("SGPR_POTRF_Q", 1); return v != 0; }
 
 size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
 
@@ -354,7 +352,7 @@ size_t ws_bytes(int n)
     const int nq = std::min(n, q_max()) / TM * TM;
     if (nq < q_min()) return 0;
     const size_t tm = (size_t)nq / TM, tn = (size_t)nq / TN;
-    return 256 + pad256(tm * tn * 4 * VS) + pad256(tn * 4 * VS) + pad256((tm + 1) * 4) + pad256(max_tasks(nq) * 8) + 256;
+    return 256 + Q_WORDS * 4 + pad256(tm * tn * 4 * VS) + pad256(tn * 4 * VS) + pad256((tm + 1) * 4) + pad256(max_tasks(nq) * 8) + 256;
 }
 
 Ws carve(void *base, int n)
@@ -362,7 +360,7 @@ Ws carve(void *base, int n)
     Ws w{};
     const size_t tm = (size_t)n / TM, tn = (size_t)n / TN;
     char *p = reinterpret_cast<char *>(((uintptr_t)base + 255) / 256 * 256);
-    w.qs = reinterpret_cast<int *>(p);            p += 256;
+    w.qs = reinterpret_cast<int *>(p);            p += Q_WORDS * 4;
     w.ver = reinterpret_cast<int *>(p);           p += pad256(tm * tn * 4 * VS);
     w.tver = reinterpret_cast<int *>(p);          p += pad256(tn * 4 * VS);
     w.zero_bytes = (size_t)(p - reinterpret_cast<char *>(w.qs));
@@ -472,6 +470,35 @@ struct QArgs {
 
 constexpr int QT = 512;
 constexpr unsigned long long Q_WAIT_LIMIT = 20ull * 100000000ull;     // 20 s of the 100 MHz real-time counter
+constexpr unsigned long long Q_GIVEUP_TICKS = 300000ull;               // 3 ms without any publish anywhere: drain this instance
+
+// is the task behind a ticket already done?  (after a rewind the head passes over tasks that were finished out of order)
+__device__ __forceinline__ bool task_done(const int *ver, const int *tver, int tn, const int *pstart, unsigned tk, unsigned tk1)
+{
+    const int type = (int)(tk >> 30), k = (int)((tk >> 21) & 511u), i = (int)((tk >> 11) & 1023u), j = (int)(tk & 2047u);
+    if (type == TASK_U)
+        return __hip_atomic_load((gint *)(ver + ((size_t)i * tn + j) * VS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (int)(tk1 & 0xffffu);
+    return __hip_atomic_load((gint *)(tver + (size_t)(2 * i) * VS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= pstart[k + 1] / (int)LEAF;
+}
+
+// between two worker instances: the ticket head goes back to the first task that is not done, the drain word is cleared
+__global__ __launch_bounds__(1024) void rewind_kernel(const QArgs a)
+{
+    __shared__ int first;
+    if (threadIdx.x == 0) first = a.ntasks;
+    __syncthreads();
+    if (__hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+        __hip_atomic_load((gint *)a.qs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.ntasks)
+        return;                                   // the instance before ran the list to its end
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int t = threadIdx.x; t < a.ntasks; t += blockDim.x)
+        if (!task_done(a.ver, a.tver, a.tn, a.pstart, a.tasks[2 * (size_t)t], a.tasks[2 * (size_t)t + 1])) { atomicMin(&first, t); break; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store((gint *)a.qs, first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((gint *)(a.qs + Q_DRAIN), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
 {
@@ -489,6 +516,18 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
     int t = sh[0];
     while (t < a.ntasks) {
         const unsigned tk = a.tasks[2 * (size_t)t], tk1 = a.tasks[2 * (size_t)t + 1];
+        // this instance is being drained (Q_DRAIN), or the task was finished before a rewind: nothing to do for this ticket
+        if (tid == 0) {
+            const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh[2] = dr ? 2 : (task_done(a.ver, a.tver, a.tn, a.pstart, tk, tk1) ? 1 : 0);
+            if (sh[2] == 1) sh[0] = atomicAdd(a.qs, 1);
+        }
+        __syncthreads();
+        const int skip = sh[2];
+        const int tskip = sh[0];
+        __syncthreads();
+        if (skip == 2) break;
+        if (skip == 1) { t = tskip; continue; }
         const int type = (int)(tk >> 30), k = (int)((tk >> 21) & 511u), i = (int)((tk >> 11) & 1023u), j = (int)(tk & 2047u);
         // update: leaf columns [ca, cb) of L; solve: panel k = columns [s0, s0 + w)
         const int ca = (int)(tk1 >> 16), cb = (int)(tk1 & 0xffffu);
@@ -517,6 +556,8 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             int ok = 1;
             bool timed_out = false;
             const unsigned long long twait0 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long tprog = twait0;       // when the progress word last changed under this wait
+            int prog = __hip_atomic_load((gint *)(a.qs + Q_PROG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 if (__all(v >= need)) break;
@@ -533,12 +574,23 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 // give up when somebody else has, or after 20 s of REAL time (a bound counted in polls would depend on how the
                 // polls are spaced, and a wave can stand still for a while without any fault of the program)
                 const int ab = __hip_atomic_load((gint *)(a.qs + Q_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                timed_out = __builtin_amdgcn_s_memrealtime() - twait0 > Q_WAIT_LIMIT;
+                const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
+                timed_out = tnow - twait0 > Q_WAIT_LIMIT;
                 if (ab != 0 || timed_out) { ok = 0; break; }
+                // nothing published anywhere for Q_GIVEUP_TICKS: somebody this grid waits for is not running.
+                // Drain the instance: the waiters leave, whoever was stranded gets a CU, finishes and leaves too.
+                const int pg = __hip_atomic_load((gint *)(a.qs + Q_PROG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (pg != prog) { prog = pg; tprog = tnow; }
+                int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!dr && tnow - tprog > Q_GIVEUP_TICKS) {
+                    __hip_atomic_store((gint *)(a.qs + Q_DRAIN), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dr = 1;
+                }
+                if (dr) { ok = 2; break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!ok && timed_out) {
+            if (ok == 0 && timed_out) {
                 // post-mortem (sgpr_probe_queue_postmortem): the first task that gave up, and which of its words were short
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 const unsigned long long short_mask = __ballot(v < need);
@@ -547,7 +599,7 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 }
             }
             if (tid == 0) {
-                if (!ok) {
+                if (ok == 0) {
                     if (timed_out) atomicCAS(a.dinfo, 0, POTRF_HANDOFF_TIMEOUT);
                     __hip_atomic_store((gint *)(a.qs + Q_ABORT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -555,7 +607,7 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             }
         }
         __syncthreads();
-        if (!sh[1]) break;                       // workgroup-uniform: the factorisation has been given up
+        if (sh[1] != 1) break;                   // workgroup-uniform: given up (0), or this instance is draining (2: the ticket stays undone)
         if (tr) a.trace[8 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
         // ---- the task's products (one call site of the k-loop body)
         const int nprod = (type == TASK_U) ? 1 : 2 * W - 1;
@@ -606,6 +658,7 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 __hip_atomic_store((gint *)(a.tver + (size_t)(2 * i) * VS), fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store((gint *)(a.tver + (size_t)(2 * i + 1) * VS), fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            __hip_atomic_fetch_add((gint *)(a.qs + Q_PROG), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tr) {
                 a.trace[8 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
                 // (word 1 of a task is < 2^27: the XCC id rides in bits 60..63)
@@ -641,8 +694,17 @@ int launch_workers(const Plan &p, const Ws &w, double *A, size_t lda, const doub
     a.trace = (g_trace && p.tasks.size() / 2 <= g_trace_cap) ? g_trace : nullptr;
     a.census = a.trace ? g_trace + TRACE_STRIDE * g_trace_cap : nullptr;
     const int grid = std::max(1, std::min(p.nworkers, (int)(p.tasks.size() / 2)));
-    hipLaunchKernelGGL(chol_queue_kernel, dim3(grid), dim3(QT), 0, st, a);
-    SGPR_CHECK_LAUNCH();
+    // Q_INSTANCES worker kernels back to back, a rewind of the ticket head between them: the first normally runs the whole
+    // list and the others leave at once (~5 us each); when an instance drains (Q_DRAIN) the next one carries on
+    const int instances = std::min(32, Q_INSTANCES + (int)(p.model_us / 8000.0));   // room for one drain per ~8 ms of the plan
+    for (int inst = 0; inst < instances; ++inst) {
+        if (inst) {
+            hipLaunchKernelGGL(rewind_kernel, dim3(1), dim3(1024), 0, st, a);
+            SGPR_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(chol_queue_kernel, dim3(grid), dim3(QT), 0, st, a);
+        SGPR_CHECK_LAUNCH();
+    }
     return 0;
 }
 
