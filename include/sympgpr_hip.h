@@ -235,7 +235,10 @@ size_t sgpr_potrf_inverses_bytes(int n);
 /* sgpr_potrf_dev keeps, per device, one high-priority side stream shared by all callers (every panel kernel of the device
  * runs on it, one at a time, whatever number of handles / host threads factor at once) and, with SGPR_POTRF_Q=1, a pair
  * of CU-masked streams.  They are created on first use and live until this call drains and destroys them (they come
- * back on demand).  Call it with no factorisation being enqueued on `device`; never needed for correctness. */
+ * back on demand).  Call it with no factorisation being enqueued on `device`; never needed for correctness -- but do call
+ * it before the process ends when a profiler is attached: with the masked streams left to the runtime's own teardown a run
+ * under rocprofv3 crashed in an exit handler (after its output was written).  The Python binding does so in an atexit hook.
+ * Touches `device` only if this library has streams on it. */
 int sgpr_release_device_streams(int device);
 /* lower Cholesky in place; only the lower triangle of A is read or written.
  * dinfo: device int, 0 or the 1-based failing minor. */

@@ -165,7 +165,23 @@ def load_library():
         raise SympGPRError("ABI version mismatch: %s is version %d, this package binds version %d -- rebuild it "
                            "(make -C sympgpr_amd/csrc)" % (path, lib.sgpr_abi_version(), ABI_VERSION))
     _LIB = lib
+    # The library keeps a few streams per device (a high-priority side stream, a CU-masked pair for the task-queue Cholesky).
+    # Hand them back while the HIP runtime is still whole: left to process teardown, a run under rocprofv3 that had used the
+    # masked streams crashed in an exit handler after the profile was written.
+    import atexit
+    atexit.register(_release_streams_at_exit)
     return lib
+
+
+def _release_streams_at_exit():
+    lib = _LIB
+    if lib is None:
+        return
+    try:
+        for dev in range(max(0, lib.sgpr_device_count())):
+            lib.sgpr_release_device_streams(dev)
+    except Exception:
+        pass
 
 
 def load_probe_library():

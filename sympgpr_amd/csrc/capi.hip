@@ -888,9 +888,7 @@ int sgpr_family_has_p(int family) { return family_has_p(family) ? 1 : 0; }
 
 int sgpr_release_device_streams(int device)
 {
-    int rc = need_device();
-    if (rc) return rc;
-    return release_device_streams(device);
+    return release_device_streams(device);      // (touches the device only if this library has streams on it)
 }
 
 int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, void *stream)

@@ -1204,6 +1204,19 @@ int release_streams(int dev)
 {
     // drain and destroy the streams this library created on `dev` (side stream, the queue driver's masked pair and its
     // event); the next factorisation creates them again.  The caller guarantees no factorisation is being enqueued.
+    {
+        // nothing of ours on this device: do not even touch it (an exit hook calls this for every device of the box)
+        bool any = false;
+        {
+            std::lock_guard<std::mutex> lock(g_side_mu);
+            any = g_side[dev] != nullptr;
+        }
+        QueueDevice &qd = g_qdev[dev];
+        std::lock_guard<std::mutex> lock(qd.mu);
+        for (int r = 0; r < 4; ++r) any = any || qd.workers[r] || qd.panels[r];
+        any = any || qd.done;
+        if (!any) return 0;
+    }
     int cur = -1;
     SGPR_HIP(hipGetDevice(&cur));
     if (cur != dev) SGPR_HIP(hipSetDevice(dev));

@@ -15,6 +15,16 @@ for tag in tags:
     d = json.loads([l for l in open(os.path.join(d0, "bench_%s_under_rocprof.json" % tag)) if l.startswith("{")][-1])
     r = d["roofline"]
     rows = list(csv.DictReader(open(os.path.join(d0, "bench_%s_kernel_stats.csv" % tag))))
+    if r["kernel"].startswith("chol_queue_kernel"):
+        # the persistent worker kernel: its first instance spans the factor stage, the instances behind it find nothing to do
+        #  -- total duration over the steps of the trace against n^3/3 per step
+        g = [x for x in rows if "chol_queue_kernel" in x["Name"]][0]
+        steps = d["steps"] + d["warmup"] + 1            # timed + warm-up + the untimed per-launch-event step
+        calls, avg_ns = int(g["Calls"]), float(g["AverageNs"])
+        ach = r["flop_per_launch"] * steps / (avg_ns * calls * 1e-9) / 1e12
+        print("| %s | 1 (+%d idle instances) | %.2f | %.2f (frac %.3f) | %.2f | %.4f | %.4f / %.4f |" % (
+            tag, round(calls / steps) - 1, steps, r["achieved"], r["frac"], ach, ach / r["achieved"], r["avg_launch_ms"], avg_ns * calls / steps * 1e-6))
+        continue
     g = [x for x in rows if "gemm_nt_kernel<256, 128>" in x["Name"]][0]
     calls, avg_ns = int(g["Calls"]), float(g["AverageNs"])
     steps = calls / r["launches"]
