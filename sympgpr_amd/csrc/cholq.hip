@@ -35,7 +35,18 @@ int q_max() { static const int v = std::min(env_int("SGPR_Q_MAX", 28672), MAX_OR
 // 2 - 6 % (n = 16384: 30.2 vs 32.2 ms; below 13312 and above 28672 it does not).  A persistent grid that fills every CU can
 // lose workgroups for a while when the platform switches the queues out and in; the workers notice
 // (nothing published anywhere for 3 ms), drain their kernel instance and the next instance carries on (Q_INSTANCES).
-bool q_on() { static const int v = env_int("SGPR_POTRF_Q", 1); return v != 0; }
+// ... and off under a profiler's counter collection (rocprofv3 --pmc / -i sets ROCPROF_COUNTER_COLLECTION): counters are
+// collected with the dispatches serialised, and the worker grid and the panel kernel have to run side by side -- the
+// look-ahead driver is profiled instead (measured: the queue path ends in its 20 s bound there).
+bool q_on()
+{
+    static const int v = [] {
+        if (!env_int("SGPR_POTRF_Q", 1)) return 0;
+        const char *cc = getenv("ROCPROF_COUNTER_COLLECTION");
+        return (cc && cc[0] && cc[0] != '0' && cc[0] != 'F' && cc[0] != 'f') ? 0 : 1;
+    }();
+    return v != 0;
+}
 
 size_t pad256(size_t b) { return (b + 255) / 256 * 256; }
 
