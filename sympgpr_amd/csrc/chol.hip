@@ -278,10 +278,10 @@ __device__ __forceinline__ bool panel_wait_ge(const int *flags, const int *idx, 
                 __builtin_amdgcn_s_sleep(16);
                 ++spins;
                 if (abort) {
-                    // task-queue driver: a long wait backs off to one look every ~7 us (hundreds of waiters polling a handful
-                    // of words flat out starve the loads of the workgroups they wait for: cholq.hip), and gives up when the
-                    // workers have, or after 20 s of REAL time
-                    if (spins > 16) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
+                    // task-queue driver: a long wait backs off to one look every ~2 us (7 us cost 1 - 2 % of the whole
+                    // factorisation: the chain is its critical path), and gives up when the workers have, or after 20 s of
+                    // REAL time
+                    if (spins > 16) __builtin_amdgcn_s_sleep(64);
                     if ((spins & 15u) == 0) {
                         if (__hip_atomic_load((gint *)abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = -1; break; }
                         if (__builtin_amdgcn_s_memrealtime() - twait0 > 20ull * 100000000ull) { ok = 0; break; }

@@ -477,6 +477,7 @@ struct QArgs {
     int *dinfo;
     unsigned long long *trace;  // 4 words per ticket, or null
     unsigned long long *census; // 2 words per worker workgroup, or null
+    unsigned pollcap;           // longest pause between two looks of a waiting workgroup, in units of ~3.4 us
 };
 
 constexpr int QT = 512;
@@ -572,13 +573,11 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             for (;;) {
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 if (__all(v >= need)) break;
-                // BACK OFF.  With a fixed short sleep, a moment in which most of the grid waits (the chain is late) has
-                // hundreds of workgroups polling a handful of words flat out, and that traffic starves the operand loads of
-                // the few workgroups everybody is waiting for: tools/queue_stress.py caught 17 running tasks that stood
-                // for 20 s with 231 pollers around them and finished within 0.1 ms of the pollers leaving.  So the pause
-                // grows from 0.2 us to ~27 us; a wait that long costs nothing beside what it waits for.
+                // Back off, but not far: the pause grows from 0.2 us to ~7 us (SGPR_Q_POLLCAP x 3.4 us).  Round 3 first let it
+                // grow to 27 us, in the belief that hundreds of pollers starve the loads of the workgroups they wait for -- the
+                // stalls that suggested it were workgroups that had been switched out; the longer pause cost 1 - 2 %.
                 ++spins;
-                const unsigned reps = spins < 5u ? 0u : (spins < 13u ? spins - 4u : 8u);
+                const unsigned reps = spins < 5u ? 0u : (spins < 13u ? min(spins - 4u, a.pollcap) : a.pollcap);
                 if (reps == 0u) __builtin_amdgcn_s_sleep(8 << 2);
                 for (unsigned r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(127);
                 if (spins < 5u) continue;
@@ -704,6 +703,8 @@ int launch_workers(const Plan &p, const Ws &w, double *A, size_t lda, const doub
     a.flags = flags; a.pstride = pflag_stride; a.inv = inv; a.dinfo = dinfo;
     a.trace = (g_trace && p.tasks.size() / 2 <= g_trace_cap) ? g_trace : nullptr;
     a.census = a.trace ? g_trace + TRACE_STRIDE * g_trace_cap : nullptr;
+    static const int pollcap = std::max(1, std::min(8, env_int("SGPR_Q_POLLCAP", 2)));
+    a.pollcap = (unsigned)pollcap;
     const int grid = std::max(1, std::min(p.nworkers, (int)(p.tasks.size() / 2)));
     // Q_INSTANCES worker kernels back to back, a rewind of the ticket head between them: the first normally runs the whole
     // list and the others leave at once (~5 us each); when an instance drains (Q_DRAIN) the next one carries on
