@@ -104,7 +104,9 @@ def kernel_code_hash():
     import hashlib
     h = hashlib.sha1()
     for f in ("common.h", "devmath.h", "pair_eval.h", os.path.join("generated", "pair_generated.h"), "leaf.h", "gemm_f64.hip",
-              "gemm_tile.h", "chol.hip", "cholq.hip", "cholq.h", "trsv.hip", "gram.hip", "gram_nd.hip", "blas_small.hip", "capi.hip"):
+              "gemm_tile.h", "chol.hip", "trsv.hip", "gram.hip", "gram_nd.hip", "blas_small.hip", "capi.hip"):
+        # (cholq.hip / cholq.h are not in: the task-queue driver runs orders 13312 .. 28672 only, the traffic profiles are of
+        # n >= 98304, where none of its code is reached)
         with open(os.path.join(ROOT, "sympgpr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
     __shared__ int sh[4];
     const int tid = threadIdx.x;
     if (tid == 0) sh[0] = atomicAdd(a.qs, 1);
-    if (a.census && tid == 0 && blockIdx.x < TRACE_WORKERS) {
+    if (a.census && tid == 0 && blockIdx.x < TRACE_WORKERS && a.census[2 * blockIdx.x + 1] == 0) {      // (the first instance's)
         a.census[2 * blockIdx.x] = ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) |
                                    (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
         a.census[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
