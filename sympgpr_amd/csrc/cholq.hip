@@ -478,6 +478,7 @@ struct QArgs {
     unsigned long long *trace;  // 4 words per ticket, or null
     unsigned long long *census; // 2 words per worker workgroup, or null
     unsigned pollcap;           // longest pause between two looks of a waiting workgroup, in units of ~3.4 us
+    int last;                   // the last worker instance of the factorisation: it never drains, it waits (up to Q_WAIT_LIMIT)
 };
 
 constexpr int QT = 512;
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 const int pg = __hip_atomic_load((gint *)(a.qs + Q_PROG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (pg != prog) { prog = pg; tprog = tnow; }
                 int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!dr && tnow - tprog > Q_GIVEUP_TICKS) {
+                if (!dr && !a.last && tnow - tprog > Q_GIVEUP_TICKS) {
                     __hip_atomic_store((gint *)(a.qs + Q_DRAIN), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     dr = 1;
                 }
@@ -714,6 +715,9 @@ int launch_workers(const Plan &p, const Ws &w, double *A, size_t lda, const doub
             hipLaunchKernelGGL(rewind_kernel, dim3(1), dim3(1024), 0, st, a);
             SGPR_CHECK_LAUNCH();
         }
+        // (the last instance does not drain: if something keeps the panel side off its CUs for longer than all the
+        // instances together -- another stream's long kernel, say -- it waits like the single instance of the first version did)
+        a.last = inst == instances - 1 ? 1 : 0;
         hipLaunchKernelGGL(chol_queue_kernel, dim3(grid), dim3(QT), 0, st, a);
         SGPR_CHECK_LAUNCH();
     }

@@ -167,3 +167,49 @@ def test_three_threads_three_handles_order_16384(oracle):
     finally:
         for f in fits:
             f.close()
+
+
+def test_queue_factorisation_beside_another_streams_long_kernels(oracle):
+    """An order the task-queue Cholesky takes (n = 16384: persistent worker grid + persistent panel kernel on CU-masked
+    streams) factored while another thread keeps the same device busy with the long launches of an order-32768
+    factorisation on its own stream (look-ahead driver): the persistent grids may be kept off their CUs, switched out and in,
+    drained and relaunched -- the results have to be bit-identical to the undisturbed ones."""
+    import threading
+    import torch
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(4242)
+
+    def problem(N):
+        q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+        l = 2.0 * np.sqrt(12 * np.pi / N)
+        return q, P, z, [l, l, 1.0], 1e-2 / l**2
+    pa, pb = problem(8192), problem(16384)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    fa, fb = SympFit("A", *pa, stream=sa.cuda_stream), SympFit("A", *pb, stream=sb.cuda_stream)
+    try:
+        ref_a = (fa.run().alpha().copy(), fa.nll())
+        ref_b = (fb.run().alpha().copy(), fb.nll())
+        errs = []
+
+        def work(f, ref, reps):
+            try:
+                for _ in range(reps):
+                    a, nll = f.run().alpha(), f.nll()
+                    assert np.array_equal(a, ref[0]) and nll == ref[1]
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(fa, ref_a, 6)), threading.Thread(target=work, args=(fb, ref_b, 2))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        idx = rng.choice(8192, 32, replace=False)
+        q, P, z, hyp, s2 = pa
+        rows = np.concatenate((idx, 8192 + idx))
+        r = oracle.build_K("A", q[idx], P[idx], q, P, hyp) @ ref_a[0] + s2 * ref_a[0][rows] - z[rows]
+        assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(z[rows])
+    finally:
+        fa.close()
+        fb.close()
