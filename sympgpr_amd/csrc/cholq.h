@@ -66,8 +66,9 @@ size_t max_tasks(int n);
 bool eligible(int n);
 
 // The ticket head is hit by a returning atomic from every workgroup at every task; the give-up word is READ by every
-// waiting workgroup.  On one cache line the readers starved the atomics: once in a few hundred factorisations a few
-// workgroups stood for as long as everybody else waited -- for them (tools/queue_stress.py).  So: a line of its own.
+// waiting workgroup: a line each.  (Round 3 took the rare stalls of this driver for memory contention for a long time and
+// spread its state words over cache lines because of that; they were workgroups that had been switched out, DESIGN 3.9.
+// The layout stays: it costs nothing.)
 constexpr int Q_ABORT = 32;
 // Third and fourth line of the state words.  Q_PROG: bumped at every publish (workers and panel strips) -- "something moved".
 // Q_DRAIN: set by a worker that has seen nothing move for Q_GIVEUP_TICKS; every worker that is NOT inside a task's
