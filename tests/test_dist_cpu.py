@@ -71,7 +71,7 @@ def _worker_nd(rank, world, port, N, nb, d, out):
 
 # the last three: N / nb is NOT a multiple of the grid dimensions -- a rank's coordinate blocks then hold different points
 # and the (2d)^2 blocks are written by one call per pair of distinct selections (sgpr_gram_nd_sel_dev)
-@pytest.mark.parametrize("world,N,nb,d", [(4, 16, 4, 2), (3, 16, 4, 2), (6, 20, 4, 2), (2, 12, 4, 3)])
+@pytest.mark.parametrize("world,N,nb,d", [(4, 16, 4, 2), (3, 16, 4, 2), (6, 20, 4, 2), (2, 12, 4, 3), (8, 28, 4, 2)])
 def test_block_cyclic_two_pairs_per_point(oracle, world, N, nb, d):
     """BASELINE config 'synthetic d=2 ... 2-D block-cyclic': the distributed driver with d canonical pairs."""
     mgr = mp.Manager()
