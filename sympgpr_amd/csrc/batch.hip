@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "gemm_tile.h"
 #include "leaf.h"
 #include "pair_eval.h"
 
@@ -235,6 +236,29 @@ __global__ __launch_bounds__(MT) void mid_build_kernel(const MidArgs a)
     }
 }
 
+// Above order 1024 a problem is factored as two panels; between them, for every problem, the rank-k update of the block that
+// is left: A22 -= L21 L21^T (lower tiles only), 128 x 128 tiles of the grid-wide MFMA kernel's LDS-DMA body (gemm_tile.h).
+struct MidSyrk {
+    double *A;            // problem b at A + b * stride (column-major, ld)
+    size_t stride, ld;
+    int k, m2;            // width of the first panel; order of the block behind it (multiples of 128)
+};
+
+__global__ __launch_bounds__(256, 2) void mid_syrk_kernel(const MidSyrk a)
+{
+    __shared__ double smem[2 * tile::BK * (2 * (128 + tile::PAD))];
+    int t = (int)blockIdx.x, r = 0;            // lower tiles row by row: row r holds r + 1 of them
+    while (t > r) { t -= r + 1; ++r; }
+    double *base = a.A + (size_t)blockIdx.y * a.stride;
+    tile::GemmArgs g{};
+    g.m = a.m2; g.n = a.m2; g.k = a.k;
+    g.alpha = -1.0; g.beta = 1.0;
+    g.A = base + a.k; g.lda = a.ld;
+    g.B = base + a.k; g.ldb = a.ld;
+    g.C = base + a.k + (size_t)a.k * a.ld; g.ldc = a.ld;
+    tile::gemm_body_dma<128, 128, 2>(g, smem, r, t);
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -386,7 +410,8 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
     const size_t o_x = 0, o_y = o_x + up256(C * npts * 8), o_z = o_y + up256(C * npts * 8), o_kc = o_z + up256(C * n * 8),
                  o_no = o_kc + up256(C * sizeof(KConst)), in_bytes = o_no + up256(C * 8);
     const size_t o_al = 0, o_nll = o_al + up256(C * n * 8), o_info = o_nll + up256(C * 8), out_bytes = o_info + up256(C * sizeof(int));
-    const size_t o_A = 0, o_inv = o_A + up256(C * img), o_fl = o_inv + up256(C * invb), scr_bytes = o_fl + up256(potrf_batch_flag_bytes(chunk));
+    const size_t o_A = 0, o_inv = o_A + up256(C * img), o_fl = o_inv + up256(C * invb), o_fl2 = o_fl + up256(potrf_batch_flag_bytes(chunk)),
+                 scr_bytes = o_fl2 + up256(potrf_batch_flag_bytes(chunk));
     Arena &ar = t_arena;
     int rc = ar.reserve(in_bytes + out_bytes + scr_bytes, in_bytes + out_bytes);
     if (rc) return rc;
@@ -422,9 +447,29 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
         default:         hipLaunchKernelGGL(mid_build_kernel<SGPR_FAM_D>, grid, dim3(MT), 0, st, a); break;
         }
         SGPR_CHECK_LAUNCH();
-        if ((rc = potrf_batch(nb, npad, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF,
-                              reinterpret_cast<int *>(dscr + o_fl), dinfo, st)))
-            return rc;
+        int *fl = reinterpret_cast<int *>(dscr + o_fl);
+        static const int two_min = [] { const char *e = getenv("SGPR_BATCH_TWO_MIN"); return e ? atoi(e) : 512; }();
+        if (npad <= two_min) {
+            if ((rc = potrf_batch(nb, npad, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF, fl, dinfo, st)))
+                return rc;
+        } else {
+            // two panels above order 512 (SGPR_BATCH_TWO_MIN): in ONE panel the last strip alone has ~W^2 / 2 products of 128^3 to
+            // do in a row (n = 2048: 3.0 ms for the launch); as W/2 + W/2 leaf columns (at most 8 first) with the update of the
+            // second half on the matrix cores between them it is ~2 ms (per fit at 16 per batch: n = 2048 947 -> 326 us,
+            // n = 1024 85 -> 75 us)
+            const int W1 = std::min(8, (W + 1) / 2), k1 = W1 * (int)LEAF, m2 = npad - k1;
+            SGPR_HIP(hipMemsetAsync(dinfo, 0, B * sizeof(int), st));
+            if ((rc = potrf_batch_panel(nb, npad, 0, W1, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF, fl,
+                                        dinfo, st)))
+                return rc;
+            const int t2 = m2 / (int)LEAF;
+            hipLaunchKernelGGL(mid_syrk_kernel, dim3((unsigned)(t2 * (t2 + 1) / 2), (unsigned)nb), dim3(256), 0, st,
+                               MidSyrk{dA, (size_t)npad * npad, (size_t)npad, k1, m2});
+            SGPR_CHECK_LAUNCH();
+            if ((rc = potrf_batch_panel(nb, npad, k1, W - W1, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF,
+                                        reinterpret_cast<int *>(dscr + o_fl2), dinfo, st)))
+                return rc;
+        }
         hipLaunchKernelGGL(mid_solve_kernel, dim3(nb), dim3(ST), 0, st, a);
         SGPR_CHECK_LAUNCH();
         const size_t from = alpha ? 0 : o_nll;

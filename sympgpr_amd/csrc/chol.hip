@@ -800,7 +800,9 @@ struct PanelBatch {
     int *flags;             // PFLAG_STRIDE ints per problem, zero on entry
     int *info;              // per problem: 0, the 1-based failing minor, or PANEL_TIMEOUT
     int *ticket;            // one int, zero on entry
-    int W, nbatch;
+    int W, nbatch;          // diagonal strips of this panel (its width / 128)
+    int R;                  // row strips from the panel's first row to the end of the matrix (>= W): W .. R-1 are solved against it
+    int k0;                 // first row / column of the panel inside its problem (a multiple of 128)
 };
 
 __global__ __launch_bounds__(LT) void panel_batch_kernel(const PanelBatch q)
@@ -811,13 +813,13 @@ __global__ __launch_bounds__(LT) void panel_batch_kernel(const PanelBatch q)
     __syncthreads();
     const int t = sh[0];
     __syncthreads();
-    const int p = t / q.W, g = t - p * q.W;
+    const int p = t / q.R, g = t - p * q.R;      // (diagonal strips 0 .. W-1 hold the smallest tickets of their problem)
     if (p >= q.nbatch) return;
     PanelArgs a{};
-    a.P = q.A + (size_t)p * q.stride_a; a.lda = q.lda;
-    a.W = a.R = a.G = q.W;
-    a.inv = q.inv + (size_t)p * q.stride_inv;
-    a.dinfo = q.info + p; a.goff = 0;
+    a.P = q.A + (size_t)p * q.stride_a + (size_t)q.k0 + (size_t)q.k0 * q.lda; a.lda = q.lda;
+    a.W = q.W; a.R = a.G = q.R;
+    a.inv = q.inv + (size_t)p * q.stride_inv + (size_t)(q.k0 / (int)LEAF) * LEAF * LEAF;
+    a.dinfo = q.info + p; a.goff = q.k0;
     a.flags = q.flags + (size_t)p * PFLAG_STRIDE;
     (void)panel_strip(a, g, s, sh);
 }
@@ -1429,10 +1431,25 @@ int potrf_batch(int nbatch, int npad, double *A, size_t stride_a, size_t lda, do
         return SGPR_E_ARG;
     }
     if (nbatch == 0) return 0;
-    SGPR_HIP(hipMemsetAsync(flags, 0, potrf_batch_flag_bytes(nbatch), st));
     SGPR_HIP(hipMemsetAsync(info, 0, (size_t)nbatch * sizeof(int), st));
-    PanelBatch q{A, stride_a, lda, inv, stride_inv, flags, info, flags + (size_t)nbatch * PFLAG_STRIDE, npad / (int)LEAF, nbatch};
-    hipLaunchKernelGGL(panel_batch_kernel, dim3((unsigned)(nbatch * q.W)), dim3(LT), 0, st, q);
+    return potrf_batch_panel(nbatch, npad, 0, npad / (int)LEAF, A, stride_a, lda, inv, stride_inv, flags, info, st);
+}
+
+// One panel of every problem: columns [k0, k0 + 128 Wd) -- its diagonal block is factored (leaf chain), the rows below it,
+// down to row npad, are solved against it.  What a blocked factorisation of the batch composes (batch.hip: two panels with a
+// batched rank-k update between them above order 1024).  `flags`: potrf_batch_flag_bytes(nbatch) bytes of scratch of this
+// call's own; info is NOT cleared here.
+int potrf_batch_panel(int nbatch, int npad, int k0, int Wd, double *A, size_t stride_a, size_t lda, double *inv, size_t stride_inv,
+                      int *flags, int *info, hipStream_t st)
+{
+    const int R = (npad - k0) / (int)LEAF;
+    if (nbatch <= 0 || k0 < 0 || k0 % LEAF != 0 || Wd < 1 || Wd > PW_MAX || Wd > R || R > PANEL_G_MAX) {
+        set_error("potrf_batch_panel: bad panel");
+        return SGPR_E_ARG;
+    }
+    SGPR_HIP(hipMemsetAsync(flags, 0, potrf_batch_flag_bytes(nbatch), st));
+    PanelBatch q{A, stride_a, lda, inv, stride_inv, flags, info, flags + (size_t)nbatch * PFLAG_STRIDE, Wd, nbatch, R, k0};
+    hipLaunchKernelGGL(panel_batch_kernel, dim3((unsigned)(nbatch * R)), dim3(LT), 0, st, q);
     SGPR_CHECK_LAUNCH();
     return 0;
 }
