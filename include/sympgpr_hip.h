@@ -34,7 +34,8 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 2   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library */
+#define SGPR_ABI_VERSION 3   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
+                                3: sgpr_fit_solve_rhs_ms (entry points added, none changed) */
 
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
@@ -181,6 +182,9 @@ int sgpr_fit_eig(sgpr_fit_t f, double *w, double *c);
 int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, double *out);
 /* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
 int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms);
+/* milliseconds of the device part of the last sgpr_fit_solve_rhs (the two triangular solves with their pack / unpack passes;
+ * the host <-> device copies of B are outside): -1 when there has been none */
+int sgpr_fit_solve_rhs_ms(sgpr_fit_t f, double *ms);
 /* device pointers of the fit (for callers that own a torch / HIP context): K/L, alpha */
 int sgpr_fit_device_ptrs(sgpr_fit_t f, void **dA, size_t *lda, void **dalpha);
 int sgpr_fit_destroy(sgpr_fit_t f);

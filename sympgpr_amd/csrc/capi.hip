@@ -65,8 +65,8 @@ struct sgpr_fit {
     size_t lwork = 0;
     bool built = false, factored = false, solved = false;
     int info = 0;
-    hipEvent_t ev[6] = {};
-    bool timed[3] = {false, false, false};
+    hipEvent_t ev[8] = {};    // build, factor, solve, solve_rhs: begin / end
+    bool timed[4] = {false, false, false, false};
 };
 
 // the strip solves bound their spins; a give-up is reported at the first call that waits for the solve
@@ -303,11 +303,11 @@ int sgpr_potrs_host(int n, const double *L, size_t ldl, double *B, size_t ldb, i
     SGPR_HIP(hipMemcpy2DAsync(dB.p, ld * sizeof(double), B, ldb * sizeof(double), ld * sizeof(double), nrhs,
                               hipMemcpyHostToDevice, st));
     if ((rc = leaf_inverses(n, dL.as<double>(), ld, dW.p, nullptr, st))) return rc;
-    if (nrhs >= 8) {  // many right-hand sides: GEMM-shaped solves on the matrix cores
+    if (nrhs >= 8 || potrs_mat_uses_strips(n, nrhs, dL.as<double>(), ld)) {  // a block of right-hand sides on the matrix cores
         DevBuf dS;
-        if ((rc = dS.alloc(ld * nrhs * sizeof(double)))) return rc;
+        if ((rc = dS.alloc(potrs_mat_scratch(n, nrhs, dL.as<double>(), ld)))) return rc;
         if ((rc = potrs_mat(n, dL.as<double>(), ld, dW.p, dB.as<double>(), ld, nrhs, dS.as<double>(), st))) return rc;
-        SGPR_HIP(hipStreamSynchronize(st));
+        if ((rc = solve_status(n, dL.as<double>(), ld, dW.p, st))) return rc;
     } else
     for (int r = 0; r < nrhs; ++r) {
         if ((rc = potrs_vec(n, dL.as<double>(), ld, dW.p, dB.as<double>() + (size_t)r * ld, st))) return rc;
@@ -624,16 +624,22 @@ int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs)
     if (rc) return rc;
     SGPR_HIP(hipMemcpy2DAsync(dB.p, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs,
                               hipMemcpyHostToDevice, f->st));
-    if (nrhs >= 8) {
+    if (nrhs >= 8 || potrs_mat_uses_strips(f->n, nrhs, f->dA, n)) {
         DevBuf dS;
-        if ((rc = dS.alloc(n * nrhs * sizeof(double)))) return rc;
+        if ((rc = dS.alloc(potrs_mat_scratch(f->n, nrhs, f->dA, n)))) return rc;
+        SGPR_HIP(hipEventRecord(f->ev[6], f->st));
         if ((rc = potrs_mat(f->n, f->dA, n, f->work, dB.as<double>(), n, nrhs, dS.as<double>(), f->st))) return rc;
-        SGPR_HIP(hipStreamSynchronize(f->st));
-    } else
-    for (int r = 0; r < nrhs; ++r) {
-        if ((rc = potrs_vec(f->n, f->dA, n, f->work, dB.as<double>() + (size_t)r * n, f->st))) return rc;
-        if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;       // the next solve reuses the hand-off words
+        SGPR_HIP(hipEventRecord(f->ev[7], f->st));
+        if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;
+    } else {
+        SGPR_HIP(hipEventRecord(f->ev[6], f->st));
+        for (int r = 0; r < nrhs; ++r) {
+            if ((rc = potrs_vec(f->n, f->dA, n, f->work, dB.as<double>() + (size_t)r * n, f->st))) return rc;
+            if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;   // the next solve reuses the hand-off words
+        }
+        SGPR_HIP(hipEventRecord(f->ev[7], f->st));
     }
+    f->timed[3] = true;
     SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, n * sizeof(double), n * sizeof(double), nrhs,
                               hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
@@ -810,6 +816,16 @@ int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double 
         if (f->timed[s]) SGPR_HIP(hipEventElapsedTime(&ms, f->ev[2 * s], f->ev[2 * s + 1]));
         *outs[s] = ms;
     }
+    return 0;
+}
+
+int sgpr_fit_solve_rhs_ms(sgpr_fit_t f, double *ms_out)
+{
+    if (!f || !ms_out) { set_error("null argument"); return SGPR_E_ARG; }
+    SGPR_HIP(hipStreamSynchronize(f->st));
+    float ms = -1.0f;
+    if (f->timed[3]) SGPR_HIP(hipEventElapsedTime(&ms, f->ev[6], f->ev[7]));
+    *ms_out = ms;
     return 0;
 }
 

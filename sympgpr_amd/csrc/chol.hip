@@ -1583,12 +1583,26 @@ int trsm_rl(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, co
     return trsm_rl_rec(m, n, L, ldl, B, ldb, 0, c);
 }
 
-// B (n x nrhs) := L^-T L^-1 B through the MFMA kernel: the right-hand sides are transposed into
-// rows (scratch, nrhs x n), X^T = B^T L^-T (forward) then X^T L^-1 (backward), transposed back.
+// Blocks of 2 .. 256 right-hand sides take the one-launch strip solves of trsm.hip (L streamed once per 64 columns);
+// more than that is compute-bound and stays with the recursion over the grid-wide MFMA kernel.  SGPR_TRSM=rec: always.
+bool potrs_mat_uses_strips(int n, int nrhs, const double *L, size_t ldl)
+{
+    return nrhs >= 2 && nrhs <= 256 && use_strips(n, L, ldl) && trsm_strips_ok(n, L, ldl);
+}
+size_t potrs_mat_scratch(int n, int nrhs, const double *L, size_t ldl)
+{
+    if (n <= 0 || nrhs <= 0) return 8;
+    return potrs_mat_uses_strips(n, nrhs, L, ldl) ? trsm_strips_scratch(n) : (size_t)n * nrhs * sizeof(double);
+}
+
+// B (n x nrhs) := L^-T L^-1 B.  Few right-hand sides: trsm.hip.  Many: through the MFMA kernel, the right-hand sides
+// transposed into rows (scratch, nrhs x n), X^T = B^T L^-T (forward) then X^T L^-1 (backward), transposed back.
 int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, size_t ldb, int nrhs,
               double *scratch, hipStream_t st)
 {
     if (n <= 0 || nrhs <= 0) return 0;
+    if (potrs_mat_uses_strips(n, nrhs, L, ldl))
+        return potrs_strips(n, L, ldl, static_cast<const double *>(work), B, ldb, nrhs, solve_state(n, work), scratch, st);
     int rc = transpose(n, nrhs, B, ldb, scratch, (size_t)nrhs, st);
     if (rc) return rc;
     if ((rc = trsm_rlt(nrhs, n, L, ldl, scratch, (size_t)nrhs, work, st))) return rc;

@@ -114,7 +114,9 @@ int potrs_vec(int n, const double *L, size_t ldl, void *work, double *b, hipStre
 int solve_status(int n, const double *L, size_t ldl, const void *work, hipStream_t st);   // syncs st; SGPR_E_HIP if a strip solve gave up
 int trsm_rl(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work, hipStream_t st);  // B := B L^-1
 int potrs_mat(int n, const double *L, size_t ldl, const void *work, double *B, size_t ldb, int nrhs, double *scratch,
-              hipStream_t st);  // B (n x nrhs) := L^-T L^-1 B; scratch: nrhs x n doubles
+              hipStream_t st);  // B (n x nrhs) := L^-T L^-1 B; scratch: potrs_mat_scratch(n, nrhs, L, ldl) bytes
+size_t potrs_mat_scratch(int n, int nrhs, const double *L, size_t ldl);
+bool potrs_mat_uses_strips(int n, int nrhs, const double *L, size_t ldl);   // the one-launch block solves of trsm.hip (hand-off words in `work`: solve_status)
 int trsv(int n, const double *L, size_t ldl, void *work, double *b, int trans, hipStream_t st);
 bool trsv_uses_strips(int n, const double *L, size_t ldl);      // potrs_vec / trsv take the one-launch strip kernels
 const int *trsv_state(int n, const void *work);                 // their 8 state words: [2], [6] != 0 = a hand-off timed out
@@ -125,6 +127,14 @@ int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hi
 bool trsv_strips_ok(int n, const double *L, size_t ldl);
 int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state /* 4 ints, zero */,
                 double *pub /* n doubles, all bytes 0xFF */, hipStream_t st);
+
+// ---- trsm.hip : triangular solves with a block of right-hand sides, one launch per solve (strips + progress counter)
+constexpr int TRSM_YLD = 80;                                      // row stride of the right-hand-side image [k][64 + 16]
+constexpr int TRSM_WG_SCRATCH = 2 * LEAF * LEAF + LEAF * TRSM_YLD;  // doubles of scratch per workgroup
+bool trsm_strips_ok(int n, const double *L, size_t ldl);
+size_t trsm_strips_scratch(int n);                                // bytes
+int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *B, size_t ldb, int nrhs, int *state /* 8 ints */,
+                 double *scratch, hipStream_t st);
 
 // ---- batch.hip : many small fits (order <= 256 each) in one launch, one workgroup per problem
 int fit_batch_max_order();

@@ -160,6 +160,12 @@ class SympFit:
         L.check(self._lib.sgpr_fit_solve_rhs(self._h, L.dptr(B), self.n, nrhs), "sgpr_fit_solve_rhs")
         return B
 
+    def solve_rhs_ms(self):
+        """Device time (ms) of the last solve_rhs: the triangular solves without the host copies of B."""
+        v = C.c_double()
+        L.check(self._lib.sgpr_fit_solve_rhs_ms(self._h, C.cast(C.byref(v), L._dp)), "sgpr_fit_solve_rhs_ms")
+        return v.value
+
     def predict_rows(self, q, P):
         q, P = L.f64(np.atleast_1d(q)), L.f64(np.atleast_1d(P))
         m = len(q)

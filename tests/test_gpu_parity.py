@@ -592,6 +592,28 @@ def test_multi_rhs_solve_on_mfma(ops, n, nrhs):
     assert np.linalg.norm(x1 - Xr[:, 0]) / np.linalg.norm(Xr[:, 0]) < 1e-12
 
 
+@pytest.mark.parametrize("n,nrhs", [(640, 2), (640, 64), (1024, 3), (1280, 64), (2304, 17), (4096, 65), (8192, 130),
+                                    (33 * 128, 64), (16384, 256)])
+def test_block_rhs_strip_solve(ops, n, nrhs):
+    """2 .. 256 right-hand sides at orders that are multiples of 128 above 512: the one-launch strip solves of trsm.hip (L streamed
+    once per 64 columns, segments handed from strip to strip), every strip count from 5 (all strips folded or nearly) to 128,
+    column counts that are not multiples of 64, several 64-column passes; against LAPACK, residual and per-column."""
+    import scipy.linalg
+    rng = np.random.default_rng(n + nrhs)
+    # a banded-dominant SPD matrix built without an n^3 host product: L0 well conditioned, A = L0 L0^T
+    L0 = np.tril(rng.standard_normal((n, n))) / np.sqrt(n)
+    L0[np.diag_indices(n)] = 1.0 + rng.uniform(0, 1, n)
+    B = rng.standard_normal((n, nrhs))
+    B[:, -1] = 0.0
+    B[n // 3, -1] = 1.0                                     # a unit vector among the right-hand sides
+    X = ops.solve_cholesky(np.asfortranarray(L0), B)
+    Xr = scipy.linalg.solve_triangular(L0.T, scipy.linalg.solve_triangular(L0, B, lower=True, check_finite=False),
+                                       lower=False, check_finite=False)
+    assert X.shape == Xr.shape
+    err = np.linalg.norm(X - Xr, axis=0) / np.linalg.norm(Xr, axis=0)
+    assert err.max() < 1e-11, (n, nrhs, err.max(), int(err.argmax()))
+
+
 # ---------------------------------------------------------------- d canonical pairs (BASELINE d = 2, 3)
 @pytest.mark.parametrize("fam,d,n,n0", [("A", 1, 37, 21), ("A", 2, 600, 70), ("C", 2, 33, 1025), ("A", 3, 130, 64),
                                         ("C", 3, 1, 5), ("B", 2, 100, 31), ("D", 2, 65, 130), ("D", 3, 20, 20),
