@@ -129,11 +129,12 @@ int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b
                 double *pub /* n doubles, all bytes 0xFF */, hipStream_t st);
 
 // ---- trsm.hip : triangular solves with a block of right-hand sides, one launch per solve (strips + progress counter)
-constexpr int TRSM_YLD = 80;                                      // row stride of the right-hand-side image [k][64 + 16]
-constexpr int TRSM_WG_SCRATCH = 2 * LEAF * LEAF + LEAF * TRSM_YLD;  // doubles of scratch per workgroup
+constexpr int TRSM_YLD = 80;                                      // row stride of the right-hand-side images [k][64 + 16]
+constexpr int TRSM_FOLD = 8;                                      // tiles next to the diagonal folded into the leaf inverse
+constexpr int TRSM_STATE_INTS = 16;                               // hand-off words of one forward + backward pair
 bool trsm_strips_ok(int n, const double *L, size_t ldl);
 size_t trsm_strips_scratch(int n);                                // bytes
-int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *B, size_t ldb, int nrhs, int *state /* 8 ints */,
+int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *B, size_t ldb, int nrhs, int *state /* TRSM_STATE_INTS ints */,
                  double *scratch, hipStream_t st);
 
 // ---- batch.hip : many small fits (order <= 256 each) in one launch, one workgroup per problem

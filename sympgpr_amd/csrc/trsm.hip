@@ -5,184 +5,239 @@
 // matmul(Kyinv, ztrain) per call (python/05_tokamak/SympGPR/sympgpr.f90:72,85,121).
 //
 // Round 3 solved this by recursion over the MFMA GEMM kernel: ~3000 dependent launches at n = 98304, most of them one
-// 64 x 128 tile.  Here it is the design of trsv.hip carried over to 64 columns: every 128-row strip (forward) / 128-column
-// strip (backward) is owned by one workgroup that streams its tiles of L ONCE for all 64 right-hand sides (LDS-DMA, double
-// buffered, 128 x 32 x 64 products per chunk on the matrix cores), strips are dealt in dependency order by a ticket, and
-// the solved 128 x 64 segments are handed from strip to strip through memory behind a progress counter.
+// 64 x 128 tile (n = 16384, 64 right-hand sides: 44.8 ms).  Here one launch per triangular solve, two classes of workgroups:
+//
+//   STREAM class (most of the chip): strip s (128 rows forward / 128 columns backward) is one task, dealt in dependency
+//   order by a ticket.  It streams the tiles of L of its strip ONCE for all 64 right-hand sides (LDS-DMA into a 3-deep ring
+//   for L and a 2-deep ring for the solved segments, 128 x 32 x 64 products per chunk on the matrix cores) up to F tiles short
+//   of the diagonal, and hands S = B_s - sum_{q < tk-F} op(L_q) Y_q to the chain.  Before that it folds the F tiles next to the
+//   diagonal into the leaf inverse, M_f = op(inv_s) op(L(s, s-+f)) (128^3 products, off the chain).
+//
+//   CHAIN class (a few dozen workgroups): task (s, c) carries columns 16 c .. 16 c + 15 of strip s through the recurrence
+//       Y_s = op(inv_s) S - sum_{f = F..1} M_f Y_{s-+f}
+//   as 128 x 128 x 16 products straight out of registers: a wave owns 16 rows, its operand fragments of M_f come from a
+//   fragment-ordered scratch image (16-byte loads), the segment it multiplies with is polled for element by element.
+//   The chain of strips therefore carries 32 MFMAs (~1.7 us) and one memory round trip per strip instead of a 128 x 128 x 64
+//   product behind a flag, an acquire and a workgroup barrier (first version of this file: 17 us per strip).
 //
 // Roofline: L is read once per triangular solve (4 n^2 B; 2 n^2 nrhs flop for the pair): at 64 right-hand sides the two
 // bounds meet (16 flop/B against a machine balance of ~13), below that the HBM read is the bound.
 //
-// Layout: the right-hand sides live in a scratch image Y[k][MS_YLD] (row k = row of the system, 64 columns + 16 of
-// padding: the rows are the LDS image of the B operand, 2 * 80 mod 64 banks = 32), solved in place: rows of strip s hold
-// B_s until strip s publishes Y_s there.
+// Layout: right-hand sides and solution are images [k][MS_YLD] (row k = row of the system, 64 columns + 16 of padding: the
+// rows are the LDS image of the B operand, 2 * 80 mod 64 banks = 32).  Three images: the input B, the published solution P
+// and the hand-over S; P and S start as all-ones bit patterns.
 //
-// The chain of strips carries ONE product per arriving segment.  With S = B_s - sum_{q < tk-2} op(L_q) Y_q (streamed):
-//     Y_s = op(inv) S - M2 Y_{s-2} - M1 Y_{s-1},    M1 = op(inv) op(L(s, s-1)),  M2 = op(inv) op(L(s, s-2))
-// M1, M2 (128^3 products) and Z = op(inv) S are formed before their segments arrive; when Y_{s-2} and then Y_{s-1} are
-// published the strip only multiplies (128 x 128 x 64, 6.8 us of one CU's matrix cores) and subtracts.
-//
-// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): producer = write-through (sc1) stores of the segment, every
-// wave drains (vmcnt(0)), workgroup barrier, one lane raises the progress counter (agent-scope atomic max); consumer = ONE
-// relaxed poll by one lane, ONE agent-scope acquire, vmcnt(0), workgroup barrier, then LDS-DMA loads.  Every strip starts
-// with such an acquire too (its CU's L1 may hold lines of rows that have been published since), and B_s itself is read
-// with sc1 loads (never allocated in L1).  A wait is always for a SMALLER ticket, whatever the residency; every wait is
-// bounded in real time and a give-up is reported through state[2] (-> SGPR_E_HIP), never a hang.
+// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility):
+//   * chain <- chain, chain <- stream (S): the data is its own signal.  8-byte write-through (sc1) stores of values that are
+//     never the all-ones pattern (NaNs are canonicalised), consumers re-load their elements (sc1) until none is the pattern
+//     ("8-byte granules"; the form trsv.hip uses).  M_f is stored (sc1) and drained before the first element of S goes out.
+//   * stream <- chain (bulk reads of published segments by LDS-DMA): per quarter a progress counter, raised behind drain +
+//     workgroup barrier; the reader polls the four counters once (one lane), ONE agent-scope acquire, vmcnt(0), barrier.
+// Every stream task also starts with an acquire.  Forward progress: chain workgroups have the lowest block ids (dispatched
+// first); a chain task waits for older chain tasks and for its own strip's stream task, a stream task for older chain tasks:
+// the oldest unfinished task of either class can always finish.  Every wait is bounded in real time; a give-up is reported
+// through state[2] (-> SGPR_E_HIP), never a hang.
 #include "common.h"
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace sgpr {
 
 namespace {
 
-constexpr int MS_T = 512;                    // 8 waves: 4 (32-row blocks) x 2 (32-column blocks) of the 128 x 64 result
+constexpr int MS_T = 512;                    // 8 waves
 constexpr int MS_NC = 64;                    // right-hand sides per pass
 constexpr int MS_BK = 32;                    // reduction depth of one staged chunk
-constexpr int MS_YLD = TRSM_YLD;             // 80: row stride of the right-hand-side image (global AND LDS)
-constexpr int AN_LD = LEAF + 16;             // "N" image of an A chunk: [k][144]  (rows contiguous in memory)
+constexpr int MS_YLD = TRSM_YLD;             // 80: row stride of the images (global AND LDS)
+constexpr int MS_F = TRSM_FOLD;              // tiles next to the diagonal that are folded into the leaf inverse
 constexpr int XT_LD = MS_BK + 2;             // "T" image of a chunk whose reduction index is contiguous in memory: [row][34]
-constexpr int A_ELEMS = MS_BK * AN_LD;       // 4608 doubles (>= 128 * 34 = 4352)
-constexpr int B_ELEMS = MS_BK * MS_YLD;      // 2560 doubles (>= 64 * 34 = 2176)
-constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
-constexpr int WG_SCRATCH = TRSM_WG_SCRATCH;  // per workgroup: M1^T, M2^T (128 x 128 each), S (128 x 80)
-static_assert(WG_SCRATCH == 2 * LEAF * LEAF + LEAF * MS_YLD, "scratch layout");
+constexpr int NPAD = 8;                      // row pad of the "N" images: [k][ROWS + 8] (2-way bank conflicts on half the lanes of a
+                                             // fragment read -- LDS is a quarter busy here -- but THREE stages of both operands fit)
+constexpr int A_ELEMS = MS_BK * (LEAF + NPAD);   // 4352 doubles: "N" image [k][136]  (= 128 * 34, the "T" image)
+constexpr int B_ELEMS = MS_BK * (MS_NC + NPAD);  // 2304 doubles: "N" image [k][72]   (>= 64 * 34 = 2176)
+constexpr int A_STAGES = 3, B_STAGES = 3;    // both operands two chunks ahead of the products: L comes from HBM, the segments
+                                             // from the Infinity Cache (one chunk ahead they stalled every chunk: 11-12 us per tile)
+constexpr int MFRAG = LEAF * LEAF;           // doubles of one folded tile M_f
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) int gi32;
 
 struct TrsmArgs {
     int T;                 // strips (n = 128 T)
+    int nchain;            // workgroups of the chain class: blockIdx.x < nchain
     const double *L;
     size_t ldl;
     const double *inv;     // leaf inverses, LEAF x LEAF each
-    double *Y;             // n x MS_YLD image: right-hand sides in, solution out
-    double *scratch;       // gridDim.x * WG_SCRATCH doubles
-    int *state;            // [0] ticket, [1] ready (strips published, in ticket order), [2] give-up flag
-    int trans;
+    const double *Bin;     // image of the right-hand sides
+    double *P;             // image of the solution, all-ones on entry
+    double *S;             // image of the hand-over stream -> chain, all-ones on entry
+    double *M;             // T * MS_F * MFRAG doubles: the folded tiles, fragment order
+    int *state;            // [0] stream ticket, [1] chain ticket, [2] give-up flag
+    int *ready;            // [c] strips whose quarter c is published (ticket order)
+    unsigned long long *dbg;   // debug builds: 16 time stamps (100 MHz) per strip, or null
 };
+
+#ifdef SGPR_TRSM_DBG
+constexpr bool TRSM_DBG = true;
+#else
+constexpr bool TRSM_DBG = false;   // per-strip time stamps (experiments: make EXTRA=-DSGPR_TRSM_DBG, SGPR_TRSM_DBG=1)
+#endif
+
+constexpr unsigned long long UNPUBLISHED = ~0ull;
+constexpr unsigned long long WAIT_LIMIT_TICKS = 500000000ull;   // 5 s of the 100 MHz real-time counter
 
 __device__ __forceinline__ void store_sc1(double *p, double v)
 {
     __hip_atomic_store((gu64 *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double load_sc1(const double *p)
+__device__ __forceinline__ void publish(double *p, double v)
 {
-    return __longlong_as_double((long long)__hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (v != v) v = __longlong_as_double(0x7FF8000000000000ll);       // never the all-ones pattern
+    store_sc1(p, v);
 }
-
+__device__ __forceinline__ unsigned long long load_bits_sc1(const double *p)
+{
+    return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void dma16(const double *src, double *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-// One operand of a 128 (or 64) x 32 chunk product.  `p` points at element (row 0, reduction index 0) of the operand,
-// `ld` is its leading dimension in memory.
-//   N: the non-reduction index is contiguous in memory (element (row, k) at row + k ld)
-//   T: the reduction index is contiguous in memory     (element (row, k) at k + row ld)
-struct Operand { const double *p; unsigned ld; };
+// ---- LDS-DMA staging.  One operand of a (ROWS x 32) chunk product; `p` points at element (row 0, reduction index 0):
+//   N: the non-reduction index is contiguous in memory (element (row, k) at row + k ld)  -> image [k][ROWS + 8]
+//   T: the reduction index is contiguous in memory     (element (row, k) at k + row ld)  -> image [row][34]
+// A wave instruction moves 64 granules of 16 B to 1 KiB of consecutive LDS; which granule a lane fetches is free, so the
+// padded images are filled in image order (pad granules re-fetch a neighbour).  The per-lane offsets depend on the
+// leading dimension only and are formed once per task.
+template <bool TR, int ROWS>
+struct Stager {
+    static constexpr int GPR = TR ? 17 : (ROWS + NPAD) / 2;                    // granules per image row
+    static constexpr int NJ = (TR ? ROWS * 17 : MS_BK * GPR) / 64;           // wave instructions per chunk
+    static constexpr int NX = (NJ + 7) / 8;                                  // per wave, at most
+    static_assert((TR ? ROWS * 17 : MS_BK * GPR) % 64 == 0, "image is a whole number of wave instructions");
+    unsigned off[NX];
+    unsigned ld;
+    __device__ __forceinline__ void init(unsigned ld_, int wave, int lane)
+    {
+        ld = ld_;
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            const int g = 64 * (wave + 8 * x) + lane, r = g / GPR, c = g - GPR * r;
+            const int cmax = TR ? 15 : ROWS / 2 - 1;
+            off[x] = (unsigned)r * ld_ + 2u * (unsigned)(c < cmax ? c : cmax);
+        }
+    }
+    // number of instructions this wave issues per chunk
+    __device__ __forceinline__ int count(int wave) const { return (NJ - 1 - wave) / 8 + 1; }
+    __device__ __forceinline__ void issue(const double *p, int kc, double *lds, int wave) const
+    {
+        const double *src = p + (TR ? (size_t)(MS_BK * kc) : (size_t)(MS_BK * kc) * ld);
+#pragma unroll
+        for (int x = 0; x < NX; ++x) {
+            const int j = wave + 8 * x;
+            if (j < NJ) dma16(src + off[x], lds + 128 * j);
+        }
+    }
+};
 
-// ---- LDS-DMA staging of chunk kc (reduction indices [32 kc, 32 kc + 32)).  A wave instruction moves 64 granules of 16 B
-// to 1 KiB of consecutive LDS; which granule a lane fetches is free, so the padded images are filled in image order.
-template <bool AT>
-__device__ __forceinline__ void issue_A(const Operand &A, int kc, double *As, int wave, int lane)
+__device__ __forceinline__ unsigned lds_addr(const void *p)
 {
-    if constexpr (!AT) {
-        // image [k][144]: instruction j = reduction index k, lanes = 128 consecutive rows
-        const double *src = A.p + (size_t)(MS_BK * kc) * A.ld + 2 * lane;
-#pragma unroll
-        for (int x = 0; x < MS_BK / 8; ++x) {
-            const int j = wave + 8 * x;
-            dma16(src + (size_t)j * A.ld, As + j * AN_LD);
-        }
-    } else {
-        // image [row][34]: granule g = 17 row + rp (rp = 16: the pad, fetched from a valid dummy address)
-        const double *src = A.p + MS_BK * kc;
-#pragma unroll
-        for (int x = 0; x < 5; ++x) {
-            const int j = wave + 8 * x;
-            if (j < (LEAF * 17) / 64) {
-                const int g = 64 * j + lane, row = g / 17, rp = g - 17 * row;
-                dma16(src + (size_t)row * A.ld + 2 * (rp < 16 ? rp : 15), As + 128 * j);
-            }
-        }
-    }
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p;
 }
-template <bool BT>
-__device__ __forceinline__ void issue_B(const Operand &B, int kc, double *Bs, int wave, int lane)
+template <int OFF>
+__device__ __forceinline__ double ds_read_f64(unsigned addr)
 {
-    if constexpr (!BT) {
-        // image [k][80]: granule g = 40 k + jp (jp >= 32: pad)
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const int j = wave + 8 * x;
-            if (j < (MS_BK * MS_YLD) / 128) {
-                const int g = 64 * j + lane, k = g / 40, jp = g - 40 * k;
-                dma16(B.p + (size_t)(MS_BK * kc + k) * B.ld + 2 * (jp < 32 ? jp : 31), Bs + 128 * j);
-            }
-        }
-    } else {
-        // image [col][34], 64 columns
-        const double *src = B.p + MS_BK * kc;
-#pragma unroll
-        for (int x = 0; x < 3; ++x) {
-            const int j = wave + 8 * x;
-            if (j < (MS_NC * 17) / 64) {
-                const int g = 64 * j + lane, col = g / 17, rp = g - 17 * col;
-                dma16(src + (size_t)col * B.ld + 2 * (rp < 16 ? rp : 15), Bs + 128 * j);
-            }
-        }
-    }
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
 }
+#define TRSM_LGKM_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // acc (this wave's 32 x 32 block of the 128 x 64 result, 2 x 2 accumulators of v_mfma_f64_16x16x4) += A chunk . B chunk
 // accumulator layout: acc[x][y][r] = element (row 32 wm + 16 x + 4 r + (lane >> 4), column 32 wn + 16 y + (lane & 15))
+// The fragment reads are explicit ds_read_b64 with counted waits, the reads of k-step kk + 1 in flight under the MFMAs of
+// k-step kk (left to itself hipcc sinks every read next to its use: read, lgkmcnt(0), four MFMAs, read, ...).
+template <bool AT, bool BT, int KK>
+__device__ __forceinline__ void read_frags(unsigned aA, unsigned aB, double (&f)[4])
+{
+    constexpr int AN = LEAF + NPAD, BN = MS_NC + NPAD;
+    f[0] = ds_read_f64<(AT ? 4 * KK : 4 * KK * AN) * 8>(aA);
+    f[1] = ds_read_f64<(AT ? 4 * KK + 16 * XT_LD : 4 * KK * AN + 16) * 8>(aA);
+    f[2] = ds_read_f64<(BT ? 4 * KK : 4 * KK * BN) * 8>(aB);
+    f[3] = ds_read_f64<(BT ? 4 * KK + 16 * XT_LD : 4 * KK * BN + 16) * 8>(aB);
+}
+__device__ __forceinline__ void mfma4(double4_t (&acc)[2][2], const double (&f)[4])
+{
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[0], f[2], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[0], f[3], acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], f[2], acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], f[3], acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
 template <bool AT, bool BT>
 __device__ __forceinline__ void compute_chunk(double4_t (&acc)[2][2], const double *As, const double *Bs, int wm, int wn, int l15,
                                               int l4)
 {
-    const double *pa = AT ? As + (32 * wm + l15) * XT_LD + l4 : As + l4 * AN_LD + 32 * wm + l15;
-    const double *pb = BT ? Bs + (32 * wn + l15) * XT_LD + l4 : Bs + l4 * MS_YLD + 32 * wn + l15;
-#pragma unroll
-    for (int kk = 0; kk < MS_BK / 4; ++kk) {
-        const double a0 = AT ? pa[4 * kk] : pa[4 * kk * AN_LD];
-        const double a1 = AT ? pa[4 * kk + 16 * XT_LD] : pa[4 * kk * AN_LD + 16];
-        const double b0 = BT ? pb[4 * kk] : pb[4 * kk * MS_YLD];
-        const double b1 = BT ? pb[4 * kk + 16 * XT_LD] : pb[4 * kk * MS_YLD + 16];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-    }
+    constexpr int AN = LEAF + NPAD, BN = MS_NC + NPAD;
+    const unsigned aA = lds_addr(AT ? As + (32 * wm + l15) * XT_LD + l4 : As + l4 * AN + 32 * wm + l15);
+    const unsigned aB = lds_addr(BT ? Bs + (32 * wn + l15) * XT_LD + l4 : Bs + l4 * BN + 32 * wn + l15);
+    double f0[4], f1[4];
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags<AT, BT, 0>(aA, aB, f0);
+    read_frags<AT, BT, 1>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
+    read_frags<AT, BT, 2>(aA, aB, f0); TRSM_LGKM_WAIT(4); mfma4(acc, f1);
+    read_frags<AT, BT, 3>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
+    read_frags<AT, BT, 4>(aA, aB, f0); TRSM_LGKM_WAIT(4); mfma4(acc, f1);
+    read_frags<AT, BT, 5>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
+    read_frags<AT, BT, 6>(aA, aB, f0); TRSM_LGKM_WAIT(4); mfma4(acc, f1);
+    read_frags<AT, BT, 7>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
+    TRSM_LGKM_WAIT(0); mfma4(acc, f1);
 }
 
 struct Ctl {
-    int *state;
+    int *state, *ready;
     int *sh;               // 2 ints of LDS
-    int known;             // strips known to be published (ticket order)
+    int known;             // strips known to be published in all four quarters (ticket order)
     int tid;
+    unsigned long long *dbg_wait;   // debug builds: [0] time of the first wait that had to poll, [1] the tile it was for
 };
 
-constexpr unsigned long long WAIT_LIMIT_TICKS = 500000000ull;   // 5 s of the 100 MHz real-time counter
+__device__ __forceinline__ bool gave_up(const int *state)
+{
+    return __hip_atomic_load((gi32 *)(state + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void give_up(int *state)
+{
+    __hip_atomic_store((gi32 *)(state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// Blocks until `need` strips are published.  All threads call it; returns false when the wait was given up.
+// Blocks until `need` strips are published (all quarters).  All threads call it; false when the wait was given up.
 __device__ __forceinline__ bool wait_ready(Ctl &c, int need)
 {
     if (c.known >= need) return true;
     if (c.tid == 0) {
         int v;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        if (TRSM_DBG && c.dbg_wait && c.dbg_wait[0] == 0) { c.dbg_wait[0] = t0; c.dbg_wait[1] = (unsigned long long)need; }
         unsigned it = 0;
         bool ok = true;
-        while ((v = __hip_atomic_load((gi32 *)(c.state + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < need) {
+        for (;;) {
+            const int v0 = __hip_atomic_load((gi32 *)(c.ready + 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v1 = __hip_atomic_load((gi32 *)(c.ready + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v2 = __hip_atomic_load((gi32 *)(c.ready + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int v3 = __hip_atomic_load((gi32 *)(c.ready + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = min(min(v0, v1), min(v2, v3));
+            if (v >= need) break;
             __builtin_amdgcn_s_sleep(2);
-            if ((++it & 63u) == 0) {
-                if (__hip_atomic_load((gi32 *)(c.state + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                    __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) { ok = false; break; }
-            }
+            if ((++it & 63u) == 0 && (gave_up(c.state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) { ok = false; break; }
         }
-        if (!ok) __hip_atomic_store((gi32 *)(c.state + 2), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) give_up(c.state);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         c.sh[0] = ok ? v : -1;
@@ -195,38 +250,64 @@ __device__ __forceinline__ bool wait_ready(Ctl &c, int need)
     return true;
 }
 
-// acc += sum over tiles q = 0 .. ntiles-1 of A_q (128 x 128) . B_q (128 x 64), chunk by chunk, the copy of chunk t + 1
-// in flight under the products of chunk t, across tile boundaries.  `tile(q, A, B)` names the operands of product q;
-// with POLL, B_q is segment q of the chain and may be read only once q + 1 strips are published.
+// acc += sum over tiles q = 0 .. ntiles-1 of A_q (128 x 128) . B_q (128 x 64), chunk by chunk: A chunks two ahead, B chunks
+// one ahead of the products, across tile boundaries.  `tile(q, pa, pb)` names the operands of product q; with POLL, B_q is
+// segment q of the chain and may be read only once q + 1 strips are published (A, the factor itself, is read ahead regardless).
 template <bool AT, bool BT, bool POLL, class TileFn>
-__device__ __forceinline__ bool stream_products(double4_t (&acc)[2][2], int ntiles, TileFn &&tile, Ctl &c, double *smem)
+__device__ __forceinline__ bool stream_products(double4_t (&acc)[2][2], int ntiles, TileFn &&tile, const Stager<AT, LEAF> &sa,
+                                                const Stager<BT, MS_NC> &sb, Ctl &c, double *smem)
 {
     const int tid = c.tid, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2, l15 = lane & 15, l4 = lane >> 4;
     const int nch = (LEAF / MS_BK) * ntiles;
-    bool primed = false;
-    Operand A{}, B{};
-    auto issue = [&](int t) {
-        const int q = t >> 2, kc = t & 3;
-        if (kc == 0) tile(q, A, B);
-        double *As = smem + (t & 1) * STAGE_ELEMS, *Bs = As + A_ELEMS;
-        issue_A<AT>(A, kc, As, wave, lane);
-        issue_B<BT>(B, kc, Bs, wave, lane);
+    double *const Aring = smem, *const Bring = smem + A_STAGES * A_ELEMS;
+    const double *pa_i = nullptr, *pb_i = nullptr;      // operands of the tile whose A / B chunks are being issued
+    int qa = -1, qb = -1;
+    const double *ta = nullptr, *tb = nullptr;
+    auto issue_a = [&](int t) {
+        if ((t >> 2) != qa) { qa = t >> 2; tile(qa, ta, tb); pa_i = ta; }
+        sa.issue(pa_i, t & 3, Aring + (t % A_STAGES) * A_ELEMS, wave);
     };
+    auto issue_b = [&](int t) {
+        if ((t >> 2) != qb) { qb = t >> 2; tile(qb, ta, tb); pb_i = tb; }
+        sb.issue(pb_i, t & 3, Bring + (t % B_STAGES) * B_ELEMS, wave);
+    };
+    const int na = sa.count(wave), nbw = sb.count(wave);
+    auto can_b = [&](int u) { return !POLL || (u & 3) != 0 || (u >> 2) < c.known; };
+    int ib = 0;                                  // next B chunk to issue
+    if (nch > 0) issue_a(0);
+    if (nch > 1) issue_a(1);
     for (int t = 0; t < nch; ++t) {
-        if (!primed) {
+        if (ib <= t) {
+            // chunk t's segment has not even been asked for (start, or the frontier): wait for it, start over
             if (POLL && (t & 3) == 0 && !wait_ready(c, (t >> 2) + 1)) return false;
-            issue(t);
+            issue_b(t);
+            ib = t + 1;
+            if (ib < nch && can_b(ib)) { issue_b(ib); ++ib; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        const bool nxt = t + 1 < nch && (!POLL || ((t + 1) & 3) != 0 || ((t + 1) >> 2) < c.known);
-        if (nxt) issue(t + 1);
-        const double *As = smem + (t & 1) * STAGE_ELEMS;
-        compute_chunk<AT, BT>(acc, As, As + A_ELEMS, wm, wn, l15, l4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        primed = nxt;
+        // steady state: B up to t + 1 is on its way or there; B(t + 2) and A(t + 2) go out now and may stay in flight
+        const bool steady = ib == t + 2 || ib == nch;
+        int fly = 0;
+        while (ib <= t + 2 && ib < nch && can_b(ib)) { issue_b(ib); ++ib; fly += nbw; }
+        if (t + 2 < nch) { issue_a(t + 2); fly += na; }
+        compute_chunk<AT, BT>(acc, Aring + (t % A_STAGES) * A_ELEMS, Bring + (t % B_STAGES) * B_ELEMS, wm, wn, l15, l4);
+        // chunk t + 1 has to be there; what went out in this iteration may stay in flight (unless it was catching up)
+        if (!steady) fly = 0;
+        switch (fly) {
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        // a bare barrier: __syncthreads() is a fence first and drains vmcnt(0) -- every copy that is meant to stay in flight
+        // (this was the whole difference between 11 us and the rate below per tile).  The LDS reads of this chunk were waited for
+        // inside compute_chunk, the copies of the next one just above.
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
     return true;
 }
@@ -239,28 +320,228 @@ __device__ __forceinline__ void zero_acc(double4_t (&acc)[2][2])
         for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
 }
 
+// position of element (i, k) of a folded tile in its fragment-ordered image: wave i / 16 reads its operand fragments of
+// k-steps 2 p, 2 p + 1 with ONE 16-byte load per lane (lane = (k & 3) * 16 + (i & 15))
+__device__ __forceinline__ int frag_index(int i, int k)
+{
+    const int w = i >> 4, kk = k >> 2, lane = (k & 3) * 16 + (i & 15);
+    return ((w * 16 + (kk >> 1)) * 64 + lane) * 2 + (kk & 1);
+}
+
+// ---------------------------------------------------------------------------------------------------- stream class
+template <bool fwd>
+__device__ __forceinline__ bool stream_task(const TrsmArgs &a, int tk, Ctl &c, double *smem)
+{
+    const int tid = c.tid, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 3, wn = wave >> 2, l15 = lane & 15, l4 = lane >> 4;
+    const int T = a.T;
+    constexpr bool AT = !fwd;            // backward: every tile of L and the leaf inverse act transposed
+    auto row_of = [&](int x, int r) { return 32 * wm + 16 * x + 4 * r + l4; };
+    auto col_of = [&](int y) { return 32 * wn + 16 * y + l15; };
+    const int s = fwd ? tk : T - 1 - tk;                 // this task's strip
+    // dependency q = 0 .. tk-1 of the strip, in the order the segments are published:
+    //   forward: tile (s, q), segment q;  backward: tile (T-1-q, s), segment T-1-q
+    auto tile_ptr = [&](int q) {
+        return fwd ? a.L + (size_t)s * LEAF + (size_t)q * LEAF * a.ldl
+                   : a.L + (size_t)(T - 1 - q) * LEAF + (size_t)s * LEAF * a.ldl;
+    };
+    auto seg_ptr = [&](int q) { return a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD; };
+    const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
+    const int nfold = tk < MS_F ? tk : MS_F, ns = tk - nfold;
+    auto stamp = [&](int i) { if (TRSM_DBG && a.dbg && tid == 0) a.dbg[16 * tk + i] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+    c.dbg_wait = (TRSM_DBG && a.dbg) ? a.dbg + 16 * tk + 8 : nullptr;
+    double4_t acc[2][2];
+    // ---- M_f = op(inv) op(tile_{tk-f}), f = 1 .. nfold, 64 columns per pass, stored in fragment order (write-through)
+    if (nfold > 0) {
+        Stager<AT, LEAF> sa;
+        Stager<fwd, MS_NC> sb;
+        sa.init(LEAF, wave, lane);
+        sb.init((unsigned)a.ldl, wave, lane);
+        for (int f = 1; f <= nfold; ++f) {
+            const double *tl = tile_ptr(tk - f);
+            double *Mf = a.M + ((size_t)s * MS_F + (f - 1)) * MFRAG;
+            for (int pass = 0; pass < 2; ++pass) {
+                zero_acc(acc);
+                // forward: B[red j][col k] = tile[j + k ldl] (reduction index contiguous: T image);
+                // backward: B[red j][col k] = tile[k + j ldl] (N image with the tile's leading dimension)
+                auto one = [&](int, const double *&pa, const double *&pb) {
+                    pa = inv_s;
+                    pb = fwd ? tl + (size_t)(64 * pass) * a.ldl : tl + 64 * pass;
+                };
+                (void)stream_products<AT, fwd, false>(acc, 1, one, sa, sb, c, smem);
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) store_sc1(Mf + frag_index(row_of(x, r), 64 * pass + col_of(y)), acc[x][y][r]);
+            }
+        }
+    }
+    stamp(1);
+    // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q
+    zero_acc(acc);
+    if (ns > 0) {
+        Stager<AT, LEAF> sa;
+        Stager<false, MS_NC> sb;
+        sa.init((unsigned)a.ldl, wave, lane);
+        sb.init(MS_YLD, wave, lane);
+        auto tl = [&](int q, const double *&pa, const double *&pb) { pa = tile_ptr(q); pb = seg_ptr(q); };
+        if (!stream_products<AT, false, true>(acc, ns, tl, sa, sb, c, smem)) return false;
+    }
+    stamp(2);
+    // ---- S = B_s - acc -> the hand-over image.  Every M_f store of this workgroup has been drained by now (each wave waits
+    // for vmcnt(0) in front of every barrier of the products above; explicitly once more here): S is the chain's signal.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const double *bs = a.Bin + (size_t)s * LEAF * MS_YLD;
+    double *ss = a.S + (size_t)s * LEAF * MS_YLD;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = row_of(x, r) * MS_YLD + col_of(y);
+                publish(ss + o, bs[o] - acc[x][y][r]);
+            }
+    stamp(3);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------- chain class
+// acc += A (this wave's 16 rows, fragments af[kk] = A[16 w + l15][4 kk + l4]) . B (128 x 16: one quarter of a segment).
+// `seg` = &image[first row of the segment][16 c].  Every wave fetches ITS 16 rows of the quarter (4 elements per lane, the
+// ones wave w of the producer published), polling until none is the all-ones pattern, and the eight waves share them through
+// LDS behind one barrier: a wave that pulls the whole 16 KB quarter by itself -- the first form -- pays ~4 us of its own memory
+// queue per product (MI355X_MICROARCH.md, handoff-payload), 2 KB cost one round trip.  Called by all waves alike.
+__device__ __forceinline__ bool quarter_product(double4_t &acc, const double (&af)[32], const double *seg, double *qbuf, int *state,
+                                                int wave, int l15, int l4)
+{
+    bool ok = true;
+    const double *src = seg + (size_t)(16 * wave + l4) * MS_YLD + l15;          // element r: row 16 w + 4 r + l4
+    unsigned long long bits[4];
+    unsigned long long t0 = 0;
+    unsigned it = 0;
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bits[r] = load_bits_sc1(src + (size_t)(4 * r) * MS_YLD);
+        const bool missing = bits[0] == UNPUBLISHED || bits[1] == UNPUBLISHED || bits[2] == UNPUBLISHED || bits[3] == UNPUBLISHED;
+        if (!__builtin_amdgcn_ballot_w64(missing)) break;
+        if (it == 0) t0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 127u) == 0 && (gave_up(state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) { ok = false; break; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qbuf[(16 * wave + 4 * r + l4) * 16 + l15] = __longlong_as_double((long long)bits[r]);
+    // (a bare barrier behind the LDS writes: __syncthreads() would also wait for the fragments of the next M_f, which are
+    // meant to arrive under this product)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // fragments b[kk] = B[4 kk + l4][l15]: rows of 16 doubles, two consecutive rows cover the 64 banks
+    const unsigned ab = lds_addr(qbuf + l4 * 16 + l15);
+    double b[32];
+    double4_t e = double4_t{0.0, 0.0, 0.0, 0.0}, o = double4_t{0.0, 0.0, 0.0, 0.0};
+    __builtin_amdgcn_sched_barrier(0);
+#define TRSM_RB(kk) b[kk] = ds_read_f64<(kk) * 4 * 16 * 8>(ab)
+#define TRSM_RB8(k0) TRSM_RB(k0); TRSM_RB(k0 + 1); TRSM_RB(k0 + 2); TRSM_RB(k0 + 3); TRSM_RB(k0 + 4); TRSM_RB(k0 + 5); TRSM_RB(k0 + 6); TRSM_RB(k0 + 7)
+#define TRSM_MM8(k0)                                                                                                    \
+    _Pragma("unroll") for (int kk = k0; kk < k0 + 8; kk += 2) {                                                         \
+        e = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], b[kk], e, 0, 0, 0);                                            \
+        o = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk + 1], b[kk + 1], o, 0, 0, 0);                                    \
+    }                                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0)
+    // eight reads ahead of the MFMAs (the LDS counter holds 15)
+    TRSM_RB8(0);
+    TRSM_RB8(8);  TRSM_LGKM_WAIT(8); TRSM_MM8(0);
+    TRSM_RB8(16); TRSM_LGKM_WAIT(8); TRSM_MM8(8);
+    TRSM_RB8(24); TRSM_LGKM_WAIT(8); TRSM_MM8(16);
+    TRSM_LGKM_WAIT(0); TRSM_MM8(24);
+#undef TRSM_RB
+#undef TRSM_RB8
+#undef TRSM_MM8
+    acc += e + o;
+    return ok;
+}
+
+template <bool fwd>
+__device__ __forceinline__ void chain_task(const TrsmArgs &a, int u, int tid, double *smem)
+{
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int T = a.T, tk = u >> 2, cq = u & 3;
+    const int s = fwd ? tk : T - 1 - tk;
+    const int nfold = tk < MS_F ? tk : MS_F;
+    const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
+    auto stamp = [&](int i) { if (TRSM_DBG && a.dbg && tid == 0 && cq == 0) a.dbg[16 * tk + i] = __builtin_amdgcn_s_memrealtime(); };
+    // two LDS images of a quarter segment, used in turn: product n + 2 writes the image product n read, and every wave has
+    // passed the barrier of product n + 1 -- behind its reads of product n -- by then
+    double *const qb0 = smem, *const qb1 = smem + LEAF * 16;
+    int nq = 0;
+    double af[32];
+    bool ok = true;
+    // Z = op(inv_s) S: fragments op(inv)[16 w + l15][4 kk + l4]
+    const int i = 16 * wave + l15;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+        const int k = 4 * kk + l4;
+        af[kk] = fwd ? inv_s[i + LEAF * k] : inv_s[k + LEAF * i];
+    }
+    // the fragments of M_f, f = nfold .. 1, one product ahead (plain 16-byte loads: these lines were stored write-through and
+    // drained before S went out, and this CU has never read them)
+    double2_t an[16];
+    auto load_m = [&](int f) {
+        const double *Mf = a.M + ((size_t)s * MS_F + (f - 1)) * MFRAG + ((size_t)(wave * 16) * 64 + lane) * 2;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) an[p] = *reinterpret_cast<const double2_t *>(Mf + (size_t)p * 128);
+    };
+    double4_t z = double4_t{0.0, 0.0, 0.0, 0.0};
+    ok &= quarter_product(z, af, a.S + (size_t)s * LEAF * MS_YLD + 16 * cq, (nq++ & 1) ? qb1 : qb0, a.state, wave, l15, l4);
+    if (nfold > 0) load_m(nfold);        // (behind the wait for S: M_f is complete once S is there)
+    stamp(4);
+    for (int f = nfold; f >= 1; --f) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) { af[2 * p] = an[p].x; af[2 * p + 1] = an[p].y; }
+        if (f > 1) load_m(f - 1);
+        const int q = tk - f;                                  // dependency q: the segment of the strip published q-th
+        const double *seg = a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD + 16 * cq;
+        double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+        ok &= quarter_product(acc, af, seg, (nq++ & 1) ? qb1 : qb0, a.state, wave, l15, l4);
+        if (f == 1) stamp(5);
+        z -= acc;
+    }
+    // publish: element (row 16 w + 4 r + l4, column 16 cq + l15)
+    double *ps = a.P + (size_t)s * LEAF * MS_YLD + (size_t)(16 * wave + l4) * MS_YLD + 16 * cq + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) publish(ps + (size_t)(4 * r) * MS_YLD, z[r]);
+    stamp(6);
+    if (!ok) give_up(a.state);
+    // the quarter's progress counter (bulk readers): behind every wave's drain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) (void)__hip_atomic_fetch_max((gi32 *)(a.ready + cq), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp(7);
+}
+
 template <bool fwd>
 __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
 {
-    __shared__ double smem[2 * STAGE_ELEMS];
+    __shared__ double smem[A_STAGES * A_ELEMS + B_STAGES * B_ELEMS];
     __shared__ int sh[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 3, wn = wave >> 2, l15 = lane & 15, l4 = lane >> 4;
-    const int T = a.T;
-    double *const Mt1 = a.scratch + (size_t)blockIdx.x * WG_SCRATCH;   // M1 stored row-major (= M1^T column-major)
-    double *const Mt2 = Mt1 + LEAF * LEAF;
-    double *const Ss = Mt2 + LEAF * LEAF;                              // S, [k][80]
-    Ctl c{a.state, sh, 0, tid};
-    constexpr bool AT = !fwd;            // backward: every tile of L and the leaf inverse act transposed
-    // element e = (x, y, r) of this lane: row i(x, r), column j(y)
-    auto row_of = [&](int x, int r) { return 32 * wm + 16 * x + 4 * r + l4; };
-    auto col_of = [&](int y) { return 32 * wn + 16 * y + l15; };
+    const int tid = threadIdx.x;
+    const bool chain = (int)blockIdx.x < a.nchain;
+    const int ntasks = chain ? 4 * a.T : a.T;
+    Ctl c{a.state, a.ready, sh, 0, tid, nullptr};
     for (;;) {
         if (tid == 0) {
-            sh[2] = atomicAdd(a.state, 1);
+            sh[2] = atomicAdd(a.state + (chain ? 1 : 0), 1);
             // what is published by now may be read without polling; the acquire also drops every line this CU's L1 holds of
             // rows that have been published since it read them
-            sh[3] = __hip_atomic_load((gi32 *)(a.state + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int v = 0x7fffffff;
+            for (int q = 0; q < 4; ++q) v = min(v, __hip_atomic_load((gi32 *)(a.ready + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            sh[3] = gave_up(a.state) ? -1 : v;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -268,98 +549,15 @@ __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
         const int tk = sh[2];
         c.known = sh[3];
         __syncthreads();
-        if (tk >= T) return;
-        const int s = fwd ? tk : T - 1 - tk;                 // this workgroup's strip
-        // dependency q = 0 .. tk-1 of the strip, in the order the segments are published:
-        //   forward: tile (s, q), segment q;  backward: tile (T-1-q, s), segment T-1-q
-        auto tile_ptr = [&](int q) {
-            return fwd ? a.L + (size_t)s * LEAF + (size_t)q * LEAF * a.ldl
-                       : a.L + (size_t)(T - 1 - q) * LEAF + (size_t)s * LEAF * a.ldl;
-        };
-        auto seg_ptr = [&](int q) { return a.Y + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD; };
-        const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
-        const int nfold = tk < 2 ? tk : 2, ns = tk - nfold;
-        double4_t acc[2][2];
-
-        // ---- M1 = op(inv) op(tile_{tk-1}), M2 = op(inv) op(tile_{tk-2}), 64 columns per pass, stored row-major
-        for (int f = 0; f < nfold; ++f) {
-            const double *tl = tile_ptr(tk - 1 - f);
-            double *Mt = f ? Mt2 : Mt1;
-            for (int pass = 0; pass < 2; ++pass) {
-                zero_acc(acc);
-                // forward: B[red j][col k] = tile[j + k ldl] (reduction index contiguous: T image);
-                // backward: B[red j][col k] = tile[k + j ldl] (N image with the tile's leading dimension)
-                auto one = [&](int, Operand &A, Operand &B) {
-                    A = Operand{inv_s, (unsigned)LEAF};
-                    B = fwd ? Operand{tl + (size_t)(64 * pass) * a.ldl, (unsigned)a.ldl} : Operand{tl + 64 * pass, (unsigned)a.ldl};
-                };
-                (void)stream_products<AT, fwd, false>(acc, 1, one, c, smem);
-#pragma unroll
-                for (int x = 0; x < 2; ++x)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Mt[row_of(x, r) * LEAF + 64 * pass + col_of(y)] = acc[x][y][r];
-            }
+        if (tk >= ntasks || c.known < 0) return;
+        if (chain) {
+            chain_task<fwd>(a, tk, tid, smem);
+        } else {
+            if (!stream_task<fwd>(a, tk, c, smem)) return;
         }
-        // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q
-        zero_acc(acc);
-        if (ns > 0) {
-            auto tl = [&](int q, Operand &A, Operand &B) {
-                A = Operand{tile_ptr(q), (unsigned)a.ldl};
-                B = Operand{seg_ptr(q), (unsigned)MS_YLD};
-            };
-            if (!stream_products<AT, false, true>(acc, ns, tl, c, smem)) return;
-        }
-        // ---- S = B_s - acc  ->  scratch;  Z = op(inv) S
-        double *ys = a.Y + (size_t)s * LEAF * MS_YLD;
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = row_of(x, r) * MS_YLD + col_of(y);
-                    Ss[o] = load_sc1(ys + o) - acc[x][y][r];
-                }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        double4_t z[2][2];
-        zero_acc(z);
-        {
-            auto one = [&](int, Operand &A, Operand &B) {
-                A = Operand{inv_s, (unsigned)LEAF};
-                B = Operand{Ss, (unsigned)MS_YLD};
-            };
-            (void)stream_products<AT, false, false>(z, 1, one, c, smem);
-        }
-        // ---- the chain: Y_{s-2} arrives -> Z -= M2 Y_{s-2};  Y_{s-1} arrives -> Z -= M1 Y_{s-1}
-        for (int f = nfold - 1; f >= 0; --f) {
-            const int q = tk - 1 - f;
-            if (!wait_ready(c, q + 1)) return;
-            zero_acc(acc);
-            auto one = [&](int, Operand &A, Operand &B) {
-                A = Operand{f ? Mt2 : Mt1, (unsigned)LEAF};      // row-major M: its reduction index is contiguous
-                B = Operand{seg_ptr(q), (unsigned)MS_YLD};
-            };
-            (void)stream_products<true, false, false>(acc, 1, one, c, smem);
-#pragma unroll
-            for (int x = 0; x < 2; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) z[x][y] -= acc[x][y];
-        }
-        // ---- publish
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) store_sc1(ys + row_of(x, r) * MS_YLD + col_of(y), z[x][y][r]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) (void)__hip_atomic_fetch_max((gi32 *)(a.state + 1), tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (this barrier is not decoration: without it hipcc folds the one-lane region above and the one-lane ticket draw at the
-        // top of the loop into an exit of an inner loop that the other 511 threads keep running -- with the OLD ticket)
+        // (this barrier is not decoration: without one behind the one-lane regions at the end of a task hipcc folds them and the
+        // one-lane ticket draw at the top of the loop into an exit of an inner loop that the other 511 threads keep running --
+        // with the OLD ticket)
         __syncthreads();
     }
 }
@@ -384,6 +582,39 @@ __global__ __launch_bounds__(256) void unpack_rhs_kernel(int n, int nc, const do
         if (k0 + tx < n) B[(size_t)(k0 + tx) + (size_t)j * ldb] = tile[j][tx];
 }
 
+static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
+{
+    (void)hipStreamSynchronize(st);
+    const int T = a.T;
+    std::vector<unsigned long long> h(16 * (size_t)T);
+    (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMemset(a.dbg, 0, h.size() * 8);
+    auto us = [&](int t, int i, int t2, int j) { return ((double)h[16 * t + i] - (double)h[16 * t2 + j]) * 0.01; };
+    auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
+    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last;
+    unsigned long long tmin = ~0ull, tmax = 0;
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < 8; ++i)
+            if (h[16 * t + i]) { tmin = std::min(tmin, h[16 * t + i]); tmax = std::max(tmax, h[16 * t + i]); }
+    int nwaited = 0;
+    for (int t = MS_F + 2; t < T; ++t) {
+        step.push_back(us(t, 6, t - 1, 6));                  // publish to publish (quarter 0)
+        prep.push_back(us(t, 1, t, 0));
+        tile.push_back(us(t, 2, t, 1) / (t - MS_F));
+        if (h[16 * t + 8] && h[16 * t + 9] > 16) { freetile.push_back(us(t, 8, t, 1) / (double)(h[16 * t + 9] - 1)); ++nwaited; }
+        else if (!h[16 * t + 8] && t - MS_F > 16) freetile.push_back(us(t, 2, t, 1) / (t - MS_F));
+        spub.push_back(us(t, 3, t, 2));
+        slead.push_back(us(t - 1, 6, t, 3));                 // S handed over how long before the predecessor published
+        zdone.push_back(us(t - 1, 6, t, 4));                 // Z formed how long before the predecessor published
+        hop.push_back(us(t, 5, t - 1, 6));                   // predecessor published -> last product done here
+        last.push_back(us(t, 6, t, 5));                      // publish
+    }
+    fprintf(stderr, "trsm %s T=%d: step %.2f us | fold %d tiles %.1f us | streamed tile %.2f us each, %.2f before the first wait (%d strips waited) | S out %.1f | "
+            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us\n",
+            what, T, med(step), MS_F, med(prep), med(tile), med(freetile), nwaited, med(spub), med(slead), med(zdone), med(hop), med(last),
+            (double)(tmax - tmin) * 0.01);
+}
+
 }  // namespace
 
 bool trsm_strips_ok(int n, const double *L, size_t ldl)
@@ -393,35 +624,48 @@ bool trsm_strips_ok(int n, const double *L, size_t ldl)
            (size_t)LEAF * ldl < ((size_t)1 << 31);
 }
 
-int trsm_strips_grid(int n) { const int T = n / LEAF; return T < 256 ? T : 256; }
-
+// bytes of scratch: three images and the folded tiles
 size_t trsm_strips_scratch(int n)
 {
-    return ((size_t)n * MS_YLD + (size_t)trsm_strips_grid(n) * WG_SCRATCH) * sizeof(double);
+    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MS_F * MFRAG) * sizeof(double);
 }
 
-// B (n x nrhs, column-major, device) := L^-T L^-1 B, 64 columns per pass through the image; `state`: 8 ints of device
-// scratch (two solves); `scratch`: trsm_strips_scratch(n) bytes.
+// B (n x nrhs, column-major, device) := L^-T L^-1 B, 64 columns per pass through the images; `state`: TRSM_STATE_INTS ints of
+// device scratch; `scratch`: trsm_strips_scratch(n) bytes.
 int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *B, size_t ldb, int nrhs, int *state,
                  double *scratch, hipStream_t st)
 {
     if (n <= 0 || nrhs <= 0) return 0;
     if (!trsm_strips_ok(n, L, ldl)) { set_error("potrs_strips: shape not supported"); return SGPR_E_ARG; }
-    const int T = n / LEAF, grid = trsm_strips_grid(n);
-    double *Y = scratch, *wg = scratch + (size_t)n * MS_YLD;
+    const int T = n / LEAF;
+    // chain class: four quarters of the strips next to the frontier, each MS_F + 1 products long
+    static const int nchain_env = [] { const char *e = getenv("SGPR_TRSM_CHAIN"); return e ? atoi(e) : 0; }();
+    int nchain = nchain_env > 0 ? nchain_env : 4 * (MS_F + 2);
+    if (nchain > 4 * T) nchain = 4 * T;
+    const int nstream = T < 256 - nchain ? T : 256 - nchain;
+    const size_t img = (size_t)n * MS_YLD;
+    double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img;
     for (int c0 = 0; c0 < nrhs; c0 += MS_NC) {
         const int nc = nrhs - c0 < MS_NC ? nrhs - c0 : MS_NC;
-        hipLaunchKernelGGL(pack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, B + (size_t)c0 * ldb, ldb, Y);
+        hipLaunchKernelGGL(pack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, B + (size_t)c0 * ldb, ldb, I0);
         SGPR_CHECK_LAUNCH();
-        SGPR_HIP(hipMemsetAsync(state, 0, 8 * sizeof(int), st));
-        TrsmArgs a{T, L, ldl, inv, Y, wg, state, 0};
-        hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(grid), dim3(MS_T), 0, st, a);
+        SGPR_HIP(hipMemsetAsync(state, 0, TRSM_STATE_INTS * sizeof(int), st));
+        SGPR_HIP(hipMemsetAsync(I1, 0xFF, 2 * img * sizeof(double), st));       // P and S of the forward solve
+        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, state, state + 8, nullptr};
+        const bool dbg = TRSM_DBG && getenv("SGPR_TRSM_DBG") != nullptr;
+        if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * 16 * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * 16 * T); }
+        hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);
         SGPR_CHECK_LAUNCH();
-        a.state = state + 4;
-        a.trans = 1;
-        hipLaunchKernelGGL(trsm_strips_kernel<false>, dim3(grid), dim3(MS_T), 0, st, a);
+        if (dbg) dbg_report(a, "forward", st);
+        // backward: in = the forward solution, out = the first image
+        SGPR_HIP(hipMemsetAsync(I0, 0xFF, img * sizeof(double), st));
+        SGPR_HIP(hipMemsetAsync(S, 0xFF, img * sizeof(double), st));
+        a.Bin = I1; a.P = I0;
+        a.state = state + 4; a.ready = state + 12;
+        hipLaunchKernelGGL(trsm_strips_kernel<false>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);
         SGPR_CHECK_LAUNCH();
-        hipLaunchKernelGGL(unpack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, Y, B + (size_t)c0 * ldb, ldb);
+        if (dbg) { dbg_report(a, "backward", st); (void)hipFree(a.dbg); }
+        hipLaunchKernelGGL(unpack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, I0, B + (size_t)c0 * ldb, ldb);
         SGPR_CHECK_LAUNCH();
     }
     return 0;
