@@ -169,6 +169,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="run the block-cyclic driver even on 1 GPU")
     ap.add_argument("--no-launch-events", action="store_true",
                     help="skip the extra untimed pass that times every GEMM launch with HIP events")
+    ap.add_argument("--nrhs", type=int, default=-1,
+                    help="right-hand sides of the extra, separately timed block solve X = L^-T L^-1 B with the cached factor "
+                         "(BASELINE config 05_tokamak: multi-RHS predict TRSM); default 64 with --d 3, else 0 = skip")
     ap.add_argument("--lower-only", action="store_true",
                     help="build only the lower triangle of K (what the factor reads) instead of the "
                          "full matrix build_K defines")
@@ -280,6 +283,20 @@ def main():
         aa = a.reshape(2 * d, n_pts).T[idx]
         resid = float(np.linalg.norm(pred + s2 * aa - zz) / np.linalg.norm(zz))
     nll = fit.nll()
+    # BASELINE config 05_tokamak's other half: a block of right-hand sides against the cached factor (what the reference does with
+    # matmul(Kyinv, ztrain) per prediction, sympgpr.f90:72,85,121).  Timed by HIP events around the device part (B already in HBM),
+    # outside the step `value` is computed from.
+    nrhs = args.nrhs if args.nrhs >= 0 else (64 if d == 3 else 0)
+    rhs = None
+    if nrhs > 0:
+        Bm = np.random.default_rng(5).standard_normal((n, nrhs))
+        Bm[:, 0] = z
+        ts = []
+        for _ in range(3):
+            Xs = fit.solve_rhs(Bm)
+            ts.append(fit.solve_rhs_ms())
+        rhs = {"nrhs": nrhs, "ms": float(np.mean(ts[1:])), "ms_all": [float(v) for v in ts],
+               "column0_vs_alpha": float(np.linalg.norm(Xs[:, 0] - a) / np.linalg.norm(a))}
     # the Gram kernel alone, back to back (outside the timed region, not part of `value`): the build
     # inside a step starts on an idle chip right after the barrier and carries that warm-up
     rep = []
@@ -352,6 +369,23 @@ def main():
                             "traffic": traffic.get("gram"), "traffic_source": traffic_source,
                             "achieved_back_to_back": out["gram_repeat_gb_s"],
                             "frac_back_to_back": out["gram_repeat_gb_s"] / HBM_PEAK_GBS}
+    if rhs:
+        passes = (rhs["nrhs"] + 63) // 64                 # L is streamed once per triangular solve per 64 columns
+        l_bytes = 8.0 * n * n * passes                    # 4 n^2 B per solve, two solves
+        flop = 2.0 * n * n * rhs["nrhs"]
+        gbs, tf = l_bytes / (rhs["ms"] * 1e-3) / 1e9, flop / (rhs["ms"] * 1e-3) / 1e12
+        floor_hbm, floor_mfma = l_bytes / HBM_PEAK_GBS / 1e6, flop / MFMA_F64_PEAK_TF / 1e9      # ms
+        out["solve_rhs"] = dict(rhs, l_read_gb_s=gbs, tflops=tf)
+        out["roofline_solve_rhs"] = {
+            "kernel": "trsm_strips_kernel (one launch per triangular solve: L streamed once per 64 right-hand sides)",
+            "bound": "mfma" if floor_mfma > floor_hbm else "hbm",
+            "achieved": tf if floor_mfma > floor_hbm else gbs, "peak": MFMA_F64_PEAK_TF if floor_mfma > floor_hbm else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if floor_mfma > floor_hbm else "GB/s",
+            "frac": (tf / MFMA_F64_PEAK_TF) if floor_mfma > floor_hbm else (gbs / HBM_PEAK_GBS),
+            "frac_hbm": gbs / HBM_PEAK_GBS, "frac_mfma": tf / MFMA_F64_PEAK_TF,
+            "floor_ms_hbm": floor_hbm, "floor_ms_mfma": floor_mfma, "traffic": None,
+            "algorithmic": "8 n^2 B read of L per forward + backward pair per 64 columns; 2 n^2 nrhs flop",
+            "timing": "HIP events around the pack, two solve launches and unpack; mean of the last 2 of 3 calls"}
     if args.cpu_sample > 0:
         cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family if d == 1 else "A", args.cpu_sample)
         with SympFit(args.family if d == 1 else "A", qs, Ps, zs, hs, s2s) as fs:

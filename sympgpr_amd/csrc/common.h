@@ -130,7 +130,7 @@ int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b
 
 // ---- trsm.hip : triangular solves with a block of right-hand sides, one launch per solve (strips + progress counter)
 constexpr int TRSM_YLD = 80;                                      // row stride of the right-hand-side images [k][64 + 16]
-constexpr int TRSM_FOLD = 8;                                      // tiles next to the diagonal folded into the leaf inverse
+constexpr int TRSM_FOLD = 5;                                      // tiles next to the diagonal folded into the leaf inverse
 constexpr int TRSM_STATE_INTS = 16;                               // hand-off words of one forward + backward pair
 bool trsm_strips_ok(int n, const double *L, size_t ldl);
 size_t trsm_strips_scratch(int n);                                // bytes

@@ -49,16 +49,35 @@ namespace {
 
 constexpr int MS_T = 512;                    // 8 waves
 constexpr int MS_NC = 64;                    // right-hand sides per pass
-constexpr int MS_BK = 32;                    // reduction depth of one staged chunk
+#ifndef SGPR_TRSM_BK
+#define SGPR_TRSM_BK 32
+#endif
+#ifndef SGPR_TRSM_NT
+#define SGPR_TRSM_NT 1
+#endif
+constexpr bool TRSM_NT = SGPR_TRSM_NT != 0;
+constexpr int MS_BK = SGPR_TRSM_BK;          // reduction depth of one staged chunk: 16 or 32
+constexpr int CPT = LEAF / MS_BK, CPT_SH = MS_BK == 16 ? 3 : 2; // chunks per tile
+static_assert((MS_BK == 16 || MS_BK == 32) && CPT == 1 << CPT_SH, "chunks per tile");
 constexpr int MS_YLD = TRSM_YLD;             // 80: row stride of the images (global AND LDS)
 constexpr int MS_F = TRSM_FOLD;              // tiles next to the diagonal that are folded into the leaf inverse
-constexpr int XT_LD = MS_BK + 2;             // "T" image of a chunk whose reduction index is contiguous in memory: [row][34]
+constexpr int XT_LD = MS_BK + 2;             // "T" image of a chunk whose reduction index is contiguous in memory: [row][MS_BK + 2]
 constexpr int NPAD = 8;                      // row pad of the "N" images: [k][ROWS + 8] (2-way bank conflicts on half the lanes of a
-                                             // fragment read -- LDS is a quarter busy here -- but THREE stages of both operands fit)
-constexpr int A_ELEMS = MS_BK * (LEAF + NPAD);   // 4352 doubles: "N" image [k][136]  (= 128 * 34, the "T" image)
-constexpr int B_ELEMS = MS_BK * (MS_NC + NPAD);  // 2304 doubles: "N" image [k][72]   (>= 64 * 34 = 2176)
-constexpr int A_STAGES = 3, B_STAGES = 3;    // both operands two chunks ahead of the products: L comes from HBM, the segments
-                                             // from the Infinity Cache (one chunk ahead they stalled every chunk: 11-12 us per tile)
+                                             // fragment read -- LDS is a quarter busy here -- but more stages fit)
+// ring slots, in doubles: the images ("T" [128][MS_BK + 2] / "N" [MS_BK][136] for L, "N" [MS_BK][72] / "T" [64][MS_BK + 2] for the
+// segments) rounded up to whole wave instructions per issuing wave
+constexpr int A_ELEMS = MS_BK == 16 ? 2304 : 4608;
+constexpr int B_ELEMS = MS_BK == 16 ? 1280 : 2304;
+// What bounds the products of a stream task on a quiet chip turned out to be INSTRUCTION ISSUE, not memory: one wave issues at
+// most one instruction per ~4 cycles, and the first forms of this loop spent 340 of them per 16 MFMAs, most on index arithmetic
+// (10-12 us per tile whatever the ring depth, the pad or the barrier form).  Hence running pointers (Copier), role-specialised
+// copies of the loop, constant vmcnt immediates, the copies issued under the MFMAs, the last MFMA group of a chunk deferred
+// behind the barrier.  With the whole chip streaming the latency of the copies counts as well: thin chunks and a deep ring for
+// L (six chunks = 104 KB in flight per CU).
+// The two operands are issued by DIFFERENT waves: vmcnt retires in order, so a wave that waits for the next chunk of the segment
+// would wait for every older copy of L too.
+constexpr int A_STAGES = MS_BK == 16 ? 7 : 3, B_STAGES = MS_BK == 16 ? 3 : 2;
+constexpr int A_W0 = 0, A_NW = 6, B_W0 = 6, B_NW = 2;   // waves 0..5 issue the copies of L, waves 6, 7 those of the segment
 constexpr int MFRAG = LEAF * LEAF;           // doubles of one folded tile M_f
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -103,10 +122,13 @@ __device__ __forceinline__ unsigned long long load_bits_sc1(const double *p)
 {
     return __hip_atomic_load((gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// NT: non-temporal (the factor's tiles are read exactly once, by one CU: streamed past the caches so that the solved segments,
+// which every later strip reads again, stay in the Infinity Cache)
+template <bool NT>
 __device__ __forceinline__ void dma16(const double *src, double *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)lds_dst, 16, 0, NT ? 2 : 0);
 }
 
 // ---- LDS-DMA staging.  One operand of a (ROWS x 32) chunk product; `p` points at element (row 0, reduction index 0):
@@ -115,34 +137,52 @@ __device__ __forceinline__ void dma16(const double *src, double *lds_dst)
 // A wave instruction moves 64 granules of 16 B to 1 KiB of consecutive LDS; which granule a lane fetches is free, so the
 // padded images are filled in image order (pad granules re-fetch a neighbour).  The per-lane offsets depend on the
 // leading dimension only and are formed once per task.
-template <bool TR, int ROWS>
-struct Stager {
-    static constexpr int GPR = TR ? 17 : (ROWS + NPAD) / 2;                    // granules per image row
-    static constexpr int NJ = (TR ? ROWS * 17 : MS_BK * GPR) / 64;           // wave instructions per chunk
-    static constexpr int NX = (NJ + 7) / 8;                                  // per wave, at most
-    static_assert((TR ? ROWS * 17 : MS_BK * GPR) % 64 == 0, "image is a whole number of wave instructions");
-    unsigned off[NX];
-    unsigned ld;
-    __device__ __forceinline__ void init(unsigned ld_, int wave, int lane)
+// The copy stream of one operand as one lane of an issuing wave sees it: running source pointers (one per wave instruction of a
+// chunk), advanced by a constant per chunk and by another constant at a tile boundary -- the tiles of a strip and the segments
+// they multiply are linear streams, so nothing is recomputed inside the product loop (an earlier form spent ~340 instructions
+// per chunk, most of them index arithmetic: at one instruction per ~4 cycles per wave that was as long as the 16 MFMAs).
+template <bool TR, int ROWS, int W0, int NW, int STAGES, int ELEMS, bool NT>
+struct Copier {
+    static constexpr int GPR = TR ? MS_BK / 2 + 1 : (ROWS + NPAD) / 2;       // granules per image row
+    static constexpr int NJ = (TR ? ROWS * GPR : MS_BK * GPR) / 64;          // wave instructions per chunk
+    static constexpr int NX = (NJ + NW - 1) / NW;                            // per issuing wave: EVERY issuing wave makes NX copies
+    static_assert((TR ? ROWS * GPR : MS_BK * GPR) % 64 == 0, "image is a whole number of wave instructions");
+    static_assert(128 * NW * NX <= ELEMS, "the padding copies land inside the ring slot");
+    const double *ptr[NX];
+    long step, adj;          // elements per chunk; extra elements at a tile boundary
+    double *dst;             // this wave's first destination in ring slot 0
+    int slot, left;          // ring slot of the next chunk, chunks left in its tile
+    // `p0`: element (row 0, reduction index 0) of the first chunk; ld: leading dimension of the operand in memory.
+    // Called by the issuing waves only.  (A list that is not a multiple of the issuing waves is padded: the extra copy re-fetches
+    // a granule into the unused tail of the slot, so that the counted waits are the same immediate for every wave of a role.)
+    __device__ __forceinline__ void init(const double *p0, unsigned ld, long step_, long adj_, double *ring, int wave, int lane)
     {
-        ld = ld_;
+        step = step_; adj = adj_; slot = 0; left = CPT;
+        const int w = wave - W0;
+        dst = ring + 128 * w;
 #pragma unroll
         for (int x = 0; x < NX; ++x) {
-            const int g = 64 * (wave + 8 * x) + lane, r = g / GPR, c = g - GPR * r;
-            const int cmax = TR ? 15 : ROWS / 2 - 1;
-            off[x] = (unsigned)r * ld_ + 2u * (unsigned)(c < cmax ? c : cmax);
+            int g = 64 * (w + NW * x) + lane;
+            if (w + NW * x >= NJ) g = lane;                                  // padding copy
+            const int r = g / GPR, c = g - GPR * r;
+            const int cmax = TR ? MS_BK / 2 - 1 : ROWS / 2 - 1;
+            ptr[x] = p0 + ((size_t)r * ld + 2u * (unsigned)(c < cmax ? c : cmax));
         }
     }
-    // number of instructions this wave issues per chunk
-    __device__ __forceinline__ int count(int wave) const { return (NJ - 1 - wave) / 8 + 1; }
-    __device__ __forceinline__ void issue(const double *p, int kc, double *lds, int wave) const
+    __device__ __forceinline__ void issue()
     {
-        const double *src = p + (TR ? (size_t)(MS_BK * kc) : (size_t)(MS_BK * kc) * ld);
+        double *d = dst + slot * ELEMS;
 #pragma unroll
         for (int x = 0; x < NX; ++x) {
-            const int j = wave + 8 * x;
-            if (j < NJ) dma16(src + off[x], lds + 128 * j);
+            dma16<NT>(ptr[x], d + 128 * NW * x);
+            ptr[x] += step;
         }
+        if (--left == 0) {
+            left = CPT;
+#pragma unroll
+            for (int x = 0; x < NX; ++x) ptr[x] += adj;
+        }
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 };
 
@@ -180,24 +220,52 @@ __device__ __forceinline__ void mfma4(double4_t (&acc)[2][2], const double (&f)[
     acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[1], f[3], acc[1][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
-template <bool AT, bool BT>
+// One chunk: MS_BK / 4 k-steps.  The MFMAs of the LAST k-step are not issued here: they are left to the next call (or to the
+// caller, behind the loop), which first asks for its own first fragments -- so the matrix cores have work while the first LDS
+// reads behind the barrier are in flight.  `pend`: fragments of the previous chunk's last k-step (valid when `have`).
+template <bool AT, bool BT, int KK, int NK>
+struct ChunkSteps {
+    // k-steps KK .. NK-1, the fragments of k-step KK - 1 in `cur`: reads of KK go out, then the MFMAs of KK - 1
+    template <class Mid>
+    static __device__ __forceinline__ void run(double4_t (&acc)[2][2], unsigned aA, unsigned aB, double (&cur)[4], double (&pend)[4], Mid &&mid)
+    {
+        if constexpr (KK == NK - 1) {
+            read_frags<AT, BT, KK>(aA, aB, pend); TRSM_LGKM_WAIT(4); mfma4(acc, cur);
+            if constexpr (KK == 1) { mid(); __builtin_amdgcn_sched_barrier(0); }
+        } else {
+            double nxt[4];
+            read_frags<AT, BT, KK>(aA, aB, nxt); TRSM_LGKM_WAIT(4); mfma4(acc, cur);
+            if constexpr (KK == 1) { mid(); __builtin_amdgcn_sched_barrier(0); }     // the copies of the chunks ahead go out under these MFMAs
+            ChunkSteps<AT, BT, KK + 1, NK>::run(acc, aA, aB, nxt, pend, mid);
+        }
+    }
+};
+template <bool AT, bool BT, class Mid>
 __device__ __forceinline__ void compute_chunk(double4_t (&acc)[2][2], const double *As, const double *Bs, int wm, int wn, int l15,
-                                              int l4)
+                                              int l4, double (&pend)[4], bool have, Mid &&mid)
 {
     constexpr int AN = LEAF + NPAD, BN = MS_NC + NPAD;
     const unsigned aA = lds_addr(AT ? As + (32 * wm + l15) * XT_LD + l4 : As + l4 * AN + 32 * wm + l15);
     const unsigned aB = lds_addr(BT ? Bs + (32 * wn + l15) * XT_LD + l4 : Bs + l4 * BN + 32 * wn + l15);
-    double f0[4], f1[4];
+    double f0[4];
     __builtin_amdgcn_sched_barrier(0);
     read_frags<AT, BT, 0>(aA, aB, f0);
-    read_frags<AT, BT, 1>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
-    read_frags<AT, BT, 2>(aA, aB, f0); TRSM_LGKM_WAIT(4); mfma4(acc, f1);
-    read_frags<AT, BT, 3>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
-    read_frags<AT, BT, 4>(aA, aB, f0); TRSM_LGKM_WAIT(4); mfma4(acc, f1);
-    read_frags<AT, BT, 5>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
-    read_frags<AT, BT, 6>(aA, aB, f0); TRSM_LGKM_WAIT(4); mfma4(acc, f1);
-    read_frags<AT, BT, 7>(aA, aB, f1); TRSM_LGKM_WAIT(4); mfma4(acc, f0);
-    TRSM_LGKM_WAIT(0); mfma4(acc, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (have) mfma4(acc, pend);
+    ChunkSteps<AT, BT, 1, MS_BK / 4>::run(acc, aA, aB, f0, pend, mid);
+    TRSM_LGKM_WAIT(0);                         // (the slot may be refilled behind the next barrier)
+}
+
+// s_waitcnt vmcnt(n) for a run-time n (the counter is an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+#define TRSM_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+    TRSM_VM(1) TRSM_VM(2) TRSM_VM(3) TRSM_VM(4) TRSM_VM(5) TRSM_VM(6) TRSM_VM(7) TRSM_VM(8) TRSM_VM(9) TRSM_VM(10)
+    TRSM_VM(11) TRSM_VM(12) TRSM_VM(13) TRSM_VM(14) TRSM_VM(15) TRSM_VM(16) TRSM_VM(17) TRSM_VM(18) TRSM_VM(19) TRSM_VM(20)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef TRSM_VM
 }
 
 struct Ctl {
@@ -250,66 +318,84 @@ __device__ __forceinline__ bool wait_ready(Ctl &c, int need)
     return true;
 }
 
-// acc += sum over tiles q = 0 .. ntiles-1 of A_q (128 x 128) . B_q (128 x 64), chunk by chunk: A chunks two ahead, B chunks
-// one ahead of the products, across tile boundaries.  `tile(q, pa, pb)` names the operands of product q; with POLL, B_q is
-// segment q of the chain and may be read only once q + 1 strips are published (A, the factor itself, is read ahead regardless).
-template <bool AT, bool BT, bool POLL, class TileFn>
-__device__ __forceinline__ bool stream_products(double4_t (&acc)[2][2], int ntiles, TileFn &&tile, const Stager<AT, LEAF> &sa,
-                                                const Stager<BT, MS_NC> &sb, Ctl &c, double *smem)
+// One operand stream of stream_products: first element, leading dimension, elements per chunk and extra elements per tile
+struct OpStream { const double *p0; unsigned ld; long step, adj; };
+
+// acc += sum over tiles q = 0 .. ntiles-1 of A_q (128 x 128) . B_q (128 x 64), chunk by chunk: the copies of A two chunks, those
+// of B one chunk ahead of the products, across tile boundaries.  With POLL, B_q is segment q of the chain and may be read
+// only once q + 1 strips are published (A, the factor itself, is read ahead regardless).
+// ROLE 0: this wave issues the copies of A, ROLE 1: those of B -- two copies of the loop, so that nothing inside it asks which.
+template <bool AT, bool BT, bool POLL, int ROLE>
+__device__ __forceinline__ bool stream_loop(double4_t (&acc)[2][2], int ntiles, const OpStream &oa, const OpStream &ob, Ctl &c,
+                                            double *smem)
 {
     const int tid = c.tid, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2, l15 = lane & 15, l4 = lane >> 4;
-    const int nch = (LEAF / MS_BK) * ntiles;
+    const int nch = CPT * ntiles;
     double *const Aring = smem, *const Bring = smem + A_STAGES * A_ELEMS;
-    const double *pa_i = nullptr, *pb_i = nullptr;      // operands of the tile whose A / B chunks are being issued
-    int qa = -1, qb = -1;
-    const double *ta = nullptr, *tb = nullptr;
-    auto issue_a = [&](int t) {
-        if ((t >> 2) != qa) { qa = t >> 2; tile(qa, ta, tb); pa_i = ta; }
-        sa.issue(pa_i, t & 3, Aring + (t % A_STAGES) * A_ELEMS, wave);
-    };
-    auto issue_b = [&](int t) {
-        if ((t >> 2) != qb) { qb = t >> 2; tile(qb, ta, tb); pb_i = tb; }
-        sb.issue(pb_i, t & 3, Bring + (t % B_STAGES) * B_ELEMS, wave);
-    };
-    const int na = sa.count(wave), nbw = sb.count(wave);
-    auto can_b = [&](int u) { return !POLL || (u & 3) != 0 || (u >> 2) < c.known; };
-    int ib = 0;                                  // next B chunk to issue
-    if (nch > 0) issue_a(0);
-    if (nch > 1) issue_a(1);
+    typedef Copier<AT, LEAF, A_W0, A_NW, A_STAGES, A_ELEMS, POLL && TRSM_NT> CA;      // POLL: the streamed tiles of L
+    typedef Copier<BT, MS_NC, B_W0, B_NW, B_STAGES, B_ELEMS, false> CB;
+    CA ca;
+    CB cb;
+    if (ROLE == 0) ca.init(oa.p0, oa.ld, oa.step, oa.adj, Aring, wave, lane);
+    else           cb.init(ob.p0, ob.ld, ob.step, ob.adj, Bring, wave, lane);
+    constexpr int NPER = ROLE == 0 ? CA::NX : CB::NX;        // copies per chunk of this wave
+    constexpr int LEAD = ROLE == 0 ? A_STAGES - 2 : B_STAGES - 2;   // chunks of this wave's operand in flight behind chunk t + 1
+    static_assert(MS_BK == 16 ? (CA::NX * (A_STAGES - 2) == 15 && CB::NX * (B_STAGES - 2) == 5)
+                              : (CA::NX * (A_STAGES - 2) == 6 && CB::NX * (B_STAGES - 2) == 0), "the steady-state vmcnt immediates below");
+    int ia = 0, ib = 0;                                      // next chunk of A / of B to be asked for
+    int blimit = POLL ? min(nch, CPT * c.known) : nch;       // chunks of B that may be asked for
+    for (; ia < nch && ia < A_STAGES - 1; ++ia)
+        if (ROLE == 0) ca.issue();
+    int sa_slot = 0, sb_slot = 0;                            // ring slots of chunk t
+    double pend[4] = {0.0, 0.0, 0.0, 0.0};                   // fragments of the last k-step of the chunk before (compute_chunk)
     for (int t = 0; t < nch; ++t) {
         if (ib <= t) {
-            // chunk t's segment has not even been asked for (start, or the frontier): wait for it, start over
-            if (POLL && (t & 3) == 0 && !wait_ready(c, (t >> 2) + 1)) return false;
-            issue_b(t);
+            // chunk t's segment has not even been asked for (start, or the frontier): wait until it may be
+            if (POLL && !wait_ready(c, (t >> CPT_SH) + 1)) return false;
+            if (POLL) blimit = min(nch, CPT * c.known);
+            if (ROLE == 1) cb.issue();
             ib = t + 1;
-            if (ib < nch && can_b(ib)) { issue_b(ib); ++ib; }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
         }
-        // steady state: B up to t + 1 is on its way or there; B(t + 2) and A(t + 2) go out now and may stay in flight
-        const bool steady = ib == t + 2 || ib == nch;
-        int fly = 0;
-        while (ib <= t + 2 && ib < nch && can_b(ib)) { issue_b(ib); ++ib; fly += nbw; }
-        if (t + 2 < nch) { issue_a(t + 2); fly += na; }
-        compute_chunk<AT, BT>(acc, Aring + (t % A_STAGES) * A_ELEMS, Bring + (t % B_STAGES) * B_ELEMS, wm, wn, l15, l4);
-        // chunk t + 1 has to be there; what went out in this iteration may stay in flight (unless it was catching up)
-        if (!steady) fly = 0;
-        switch (fly) {
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        // chunk t has landed (this wave's share: younger copies stay in flight), and every wave is done with chunk t - 1
+        {
+            const int ahead = (ROLE == 0 ? ia : ib) - (t + 1);
+            if (ahead == LEAD) {
+                if (MS_BK == 16) {
+                    if (ROLE == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                    else           asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                } else {
+                    if (ROLE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else {
+                wait_vmcnt(NPER * ahead);
+            }
         }
-        // a bare barrier: __syncthreads() is a fence first and drains vmcnt(0) -- every copy that is meant to stay in flight
-        // (this was the whole difference between 11 us and the rate below per tile).  The LDS reads of this chunk were waited for
-        // inside compute_chunk, the copies of the next one just above.
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        compute_chunk<AT, BT>(acc, Aring + sa_slot * A_ELEMS, Bring + sb_slot * B_ELEMS, wm, wn, l15, l4, pend, t > 0, [&]() {
+            // ... whose ring slots take the next copies
+            if (ia < nch) { if (ROLE == 0) ca.issue(); ++ia; }
+            const int lim = min(blimit, t + B_STAGES);
+            while (ib < lim) { if (ROLE == 1) cb.issue(); ++ib; }
+        });
+        sa_slot = sa_slot + 1 == A_STAGES ? 0 : sa_slot + 1;
+        sb_slot = sb_slot + 1 == B_STAGES ? 0 : sb_slot + 1;
     }
+    if (nch > 0) mfma4(acc, pend);
+    // every wave is done with the last chunk before anybody refills the rings
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     return true;
+}
+template <bool AT, bool BT, bool POLL>
+__device__ __forceinline__ bool stream_products(double4_t (&acc)[2][2], int ntiles, const OpStream &oa, const OpStream &ob, Ctl &c,
+                                                double *smem)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+    return wave < A_NW ? stream_loop<AT, BT, POLL, 0>(acc, ntiles, oa, ob, c, smem)
+                       : stream_loop<AT, BT, POLL, 1>(acc, ntiles, oa, ob, c, smem);
 }
 
 __device__ __forceinline__ void zero_acc(double4_t (&acc)[2][2])
@@ -353,42 +439,35 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, int tk, Ctl &c, d
     c.dbg_wait = (TRSM_DBG && a.dbg) ? a.dbg + 16 * tk + 8 : nullptr;
     double4_t acc[2][2];
     // ---- M_f = op(inv) op(tile_{tk-f}), f = 1 .. nfold, 64 columns per pass, stored in fragment order (write-through)
-    if (nfold > 0) {
-        Stager<AT, LEAF> sa;
-        Stager<fwd, MS_NC> sb;
-        sa.init(LEAF, wave, lane);
-        sb.init((unsigned)a.ldl, wave, lane);
-        for (int f = 1; f <= nfold; ++f) {
-            const double *tl = tile_ptr(tk - f);
-            double *Mf = a.M + ((size_t)s * MS_F + (f - 1)) * MFRAG;
-            for (int pass = 0; pass < 2; ++pass) {
-                zero_acc(acc);
-                // forward: B[red j][col k] = tile[j + k ldl] (reduction index contiguous: T image);
-                // backward: B[red j][col k] = tile[k + j ldl] (N image with the tile's leading dimension)
-                auto one = [&](int, const double *&pa, const double *&pb) {
-                    pa = inv_s;
-                    pb = fwd ? tl + (size_t)(64 * pass) * a.ldl : tl + 64 * pass;
-                };
-                (void)stream_products<AT, fwd, false>(acc, 1, one, sa, sb, c, smem);
+    for (int f = 1; f <= nfold; ++f) {
+        const double *tl = tile_ptr(tk - f);
+        double *Mf = a.M + ((size_t)s * MS_F + (f - 1)) * MFRAG;
+        for (int pass = 0; pass < 2; ++pass) {
+            zero_acc(acc);
+            // A = op(inv): forward N image (rows contiguous), backward T image (the inverse acts transposed).
+            // forward: B[red j][col k] = tile[j + k ldl] (reduction index contiguous: T image);
+            // backward: B[red j][col k] = tile[k + j ldl] (N image with the tile's leading dimension)
+            const OpStream oa{inv_s, (unsigned)LEAF, fwd ? (long)MS_BK * LEAF : (long)MS_BK, 0};
+            const OpStream ob{fwd ? tl + (size_t)(64 * pass) * a.ldl : tl + 64 * pass, (unsigned)a.ldl,
+                              fwd ? (long)MS_BK : (long)MS_BK * (long)a.ldl, 0};
+            (void)stream_products<AT, fwd, false>(acc, 1, oa, ob, c, smem);
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+            for (int x = 0; x < 2; ++x)
 #pragma unroll
-                    for (int y = 0; y < 2; ++y)
+                for (int y = 0; y < 2; ++y)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) store_sc1(Mf + frag_index(row_of(x, r), 64 * pass + col_of(y)), acc[x][y][r]);
-            }
+                    for (int r = 0; r < 4; ++r) store_sc1(Mf + frag_index(row_of(x, r), 64 * pass + col_of(y)), acc[x][y][r]);
         }
     }
     stamp(1);
-    // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q
+    // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q.  Both operands are linear streams: forward, tile (s, q + 1) follows
+    // tile (s, q) 128 columns on and segment q + 1 follows segment q; backward, tile (T-2-q, s) and segment T-2-q lie 128 rows
+    // BEFORE their predecessors (256 rows back from where the eighth chunk ended).
     zero_acc(acc);
     if (ns > 0) {
-        Stager<AT, LEAF> sa;
-        Stager<false, MS_NC> sb;
-        sa.init((unsigned)a.ldl, wave, lane);
-        sb.init(MS_YLD, wave, lane);
-        auto tl = [&](int q, const double *&pa, const double *&pb) { pa = tile_ptr(q); pb = seg_ptr(q); };
-        if (!stream_products<AT, false, true>(acc, ns, tl, sa, sb, c, smem)) return false;
+        const OpStream oa{tile_ptr(0), (unsigned)a.ldl, fwd ? (long)MS_BK * (long)a.ldl : (long)MS_BK, fwd ? 0L : -2L * LEAF};
+        const OpStream ob{seg_ptr(0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
+        if (!stream_products<AT, false, true>(acc, ns, oa, ob, c, smem)) return false;
     }
     stamp(2);
     // ---- S = B_s - acc -> the hand-over image.  Every M_f store of this workgroup has been drained by now (each wave waits
