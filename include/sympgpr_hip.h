@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SGPR_ABI_VERSION 3   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
-                                3: sgpr_fit_solve_rhs_ms (entry points added, none changed) */
+                                3: sgpr_fit_solve_rhs_ms, sgpr_potrf_info_dev (entry points added, none changed) */
 
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
@@ -237,8 +237,8 @@ size_t sgpr_potrf_workspace(int n);
  * there -- what a distributed driver has to send along with a diagonal block.  The rest is scratch. */
 size_t sgpr_potrf_inverses_bytes(int n);
 /* sgpr_potrf_dev keeps, per device, one high-priority side stream shared by all callers (every panel kernel of the device
- * runs on it, one at a time, whatever number of handles / host threads factor at once) and, with SGPR_POTRF_Q=1, a pair
- * of CU-masked streams.  They are created on first use and live until this call drains and destroys them (they come
+ * runs on it, one at a time, whatever number of handles / host threads factor at once) and, for the orders the task-queue
+ * driver takes (13312 .. 28672 unless SGPR_POTRF_Q=0), a pair of CU-masked streams.  They are created on first use and live until this call drains and destroys them (they come
  * back on demand).  Call it with no factorisation being enqueued on `device`; never needed for correctness -- but do call
  * it before the process ends when a profiler is attached: with the masked streams left to the runtime's own teardown a run
  * under rocprofv3 crashed in an exit handler (after its output was written).  The Python binding does so in an atexit hook.
@@ -248,6 +248,11 @@ int sgpr_release_device_streams(int device);
  * dinfo: device int, 0 or the 1-based failing minor. */
 int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo,
                    void *stream);
+/* What the value a caller has read back from `dinfo` means: 0 and LAPACK-style positive values come back unchanged; a negative
+ * value is an internal give-up (a bounded wait between the persistent kernels of the factorisation ran out: A is NOT factored,
+ * restore it and call sgpr_potrf_dev again) -> SGPR_E_HIP, and the task-queue driver is switched off on `stream`'s device, so the
+ * retry takes the launch-per-step driver.  (The fit handle and sgpr_potrf_host do this retry themselves.) */
+int sgpr_potrf_info_dev(int info, void *stream);
 /* B (m x n) := B L^-T with L (n x n) lower, its diagonal-leaf inverses in `work` as left by
  * sgpr_potrf_dev on that L (the panel solve of a right-looking step). */
 int sgpr_trsm_rlt_dev(int m, int n, const double *L, size_t ldl, double *B, size_t ldb,

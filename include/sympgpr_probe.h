@@ -63,6 +63,9 @@ int sgpr_probe_queue_trace_clear(void);   /* zero the stamps between two factori
 /* state words of the last task-queue factorisation of this process on stderr (ticket head, abort word, the first
  * task / panel strip that gave up waiting, version counters); returns the abort word */
 int sgpr_probe_queue_postmortem(int always);
+/* TESTS ONLY: while on, every task-queue factorisation of this process gives up before it starts (the give-up word is raised and
+ * the factor's info word set as by a hand-off that timed out) -- to exercise the callers' retry with the other driver */
+int sgpr_probe_queue_force_giveup(int on);
 
 /* co-residency census of two concurrent kernels (A: na workgroups of threads_a threads with lds_a bytes of LDS spinning
  * spin_a us on one stream, B likewise on a second, high-priority stream; optional CU masks): per workgroup XCC id,

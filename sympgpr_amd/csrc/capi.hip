@@ -272,10 +272,17 @@ int sgpr_potrf_host(int n, double *A, size_t lda)
         return rc;
     SGPR_HIP(hipMemcpy2DAsync(dA.p, ld * sizeof(double), A, lda * sizeof(double), ld * sizeof(double), n,
                               hipMemcpyHostToDevice, st));
-    if ((rc = potrf(n, dA.as<double>(), ld, dW.p, potrf_workspace(n), dI.as<int>(), st))) return rc;
-    if ((rc = zero_strict_upper(n, dA.as<double>(), ld, st))) return rc;
     int info = 0;
-    SGPR_HIP(hipMemcpyAsync(&info, dI.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = potrf(n, dA.as<double>(), ld, dW.p, potrf_workspace(n), dI.as<int>(), st))) return rc;
+        SGPR_HIP(hipMemcpyAsync(&info, dI.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        SGPR_HIP(hipStreamSynchronize(st));
+        if (info != POTRF_HANDOFF_TIMEOUT || attempt || !potrf_queue_mark_failed(st)) break;
+        // the task-queue driver gave up: the caller's matrix is still on the host -- once more, with the look-ahead driver
+        SGPR_HIP(hipMemcpy2DAsync(dA.p, ld * sizeof(double), A, lda * sizeof(double), ld * sizeof(double), n,
+                                  hipMemcpyHostToDevice, st));
+    }
+    if ((rc = zero_strict_upper(n, dA.as<double>(), ld, st))) return rc;
     SGPR_HIP(hipStreamSynchronize(st));
     if (info) return info_status(info);
     SGPR_HIP(hipMemcpy2D(A, lda * sizeof(double), dA.p, ld * sizeof(double), ld * sizeof(double), n,
@@ -537,6 +544,18 @@ int sgpr_fit_factor(sgpr_fit_t f)
     f->built = false;  // K has been overwritten by L
     SGPR_HIP(hipMemcpyAsync(&f->info, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
+    if (f->info == POTRF_HANDOFF_TIMEOUT && potrf_queue_mark_failed(f->st)) {
+        // The task-queue driver gave up (a hand-off between its persistent kernels ran into its time limit): Ky is half
+        // overwritten, but the handle holds what it was built from.  Build it again and factor with the look-ahead driver,
+        // which this device uses from now on.  (Once: a second give-up is an error.)
+        if ((rc = fit_build_impl(f, f->flags & SGPR_FIT_LOWER_ONLY))) return rc;
+        SGPR_HIP(hipEventRecord(f->ev[2], f->st));
+        if ((rc = potrf(f->n, f->dA, (size_t)f->n, f->work, f->lwork, f->dinfo, f->st))) return rc;
+        SGPR_HIP(hipEventRecord(f->ev[3], f->st));
+        f->built = false;
+        SGPR_HIP(hipMemcpyAsync(&f->info, f->dinfo, sizeof(int), hipMemcpyDeviceToHost, f->st));
+        SGPR_HIP(hipStreamSynchronize(f->st));
+    }
     f->factored = f->info == 0;
     return info_status(f->info);
 }
@@ -912,6 +931,13 @@ int sgpr_potrf_dev(int n, double *A, size_t lda, void *work, size_t lwork, int *
     int rc = need_device();
     if (rc) return rc;
     return potrf(n, A, lda, work, lwork, dinfo, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_potrf_info_dev(int info, void *stream)
+{
+    if (info >= 0) return info;
+    if (info == POTRF_HANDOFF_TIMEOUT) (void)potrf_queue_mark_failed(static_cast<hipStream_t>(stream));
+    return info_status(info);
 }
 
 int sgpr_trsm_rlt_dev(int m, int n, const double *L, size_t ldl, double *B, size_t ldb,

@@ -1093,9 +1093,43 @@ struct QueueDevice {
     hipEvent_t done = nullptr;                 // end of the last queue factorisation enqueued on this device
     int ncu = 0;
     hipStream_t workers[4] = {}, panels[4] = {};   // by R - 1 (CUs per XCD set aside for the panel kernels)
-    bool failed = false;                       // masked streams cannot be had: the look-ahead driver takes over
+    bool overlap_ok[4] = {};                   // ... and whether kernels on the pair have been SEEN to run side by side
+    bool failed = false;                       // masked streams cannot be had, kernels on them do not overlap, or a queue
+                                               // factorisation gave up: the look-ahead driver takes over (until the streams are released)
 };
 QueueDevice g_qdev[64];
+
+// Two one-thread kernels, one on each stream of the pair, that wait for each other (bounded: 50 ms).  The task-queue
+// factorisation is two persistent kernels that hand work to each other: where dispatches are serialised -- a profiler collecting
+// counters, HIP_LAUNCH_BLOCKING, AMD_SERIALIZE_KERNEL, a debugger -- the second never starts while the first waits, and the
+// factorisation would end in its time limit with A half overwritten.  Tried once per stream pair; w: 4 ints, zero.
+__global__ void overlap_probe_kernel(int *w, int me)
+{
+    __hip_atomic_store((gint *)(w + me), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int seen = 0;
+    while (!(seen = __hip_atomic_load((gint *)(w + 1 - me), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        __builtin_amdgcn_s_sleep(32);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) break;
+    }
+    w[2 + me] = seen ? 1 : 2;
+}
+static bool queue_overlap_ok(hipStream_t sw, hipStream_t sp)
+{
+    int *w = nullptr;
+    if (hipMalloc((void **)&w, 4 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    int h[4] = {0, 0, 0, 0};
+    bool ok = hipMemset(w, 0, sizeof(h)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(1), 0, sp, w, 0);
+        hipLaunchKernelGGL(overlap_probe_kernel, dim3(1), dim3(1), 0, sw, w, 1);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(sp) == hipSuccess && hipStreamSynchronize(sw) == hipSuccess &&
+             hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[2] == 1 && h[3] == 1;
+    }
+    (void)hipFree(w);
+    (void)hipGetLastError();
+    return ok;
+}
 
 int queue_streams(QueueDevice &qd, int dev, int R, hipStream_t *sw, hipStream_t *sp)
 {
@@ -1115,9 +1149,29 @@ int queue_streams(QueueDevice &qd, int dev, int R, hipStream_t *sw, hipStream_t 
             return SGPR_E_HIP;
         }
     }
+    if (!qd.overlap_ok[R - 1]) {
+        if (!queue_overlap_ok(qd.workers[R - 1], qd.panels[R - 1])) {
+            qd.failed = true;
+            return SGPR_E_HIP;
+        }
+        qd.overlap_ok[R - 1] = true;
+    }
     *sw = qd.workers[R - 1];
     *sp = qd.panels[R - 1];
     return 0;
+}
+
+// A queue factorisation on `st`'s device has given up (POTRF_HANDOFF_TIMEOUT read back by the caller): no further one is
+// started there until the streams are released.  Returns true when the queue was in use (a retry will take the other driver).
+bool potrf_queue_mark_failed(hipStream_t st)
+{
+    int dev = -1;
+    if ((st ? hipStreamGetDevice(st, &dev) : hipGetDevice(&dev)) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    QueueDevice &qd = g_qdev[dev];
+    std::lock_guard<std::mutex> lock(qd.mu);
+    const bool was_on = !qd.failed;
+    qd.failed = true;
+    return was_on;
 }
 
 // returns 1 when the queue form cannot be used here (the caller falls back to the look-ahead driver), < 0 on errors
@@ -1158,6 +1212,10 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     int rc;
     SGPR_HIP(hipStreamWaitEvent(su, qd.done, 0));               // after the previous queue factorisation on this device
     if ((rc = cholq::prepare(*plan, ws, su))) return rc;
+    if (cholq::forced_giveup()) {                                // tests only: the give-up word is up, and so is what a timed-out waiter leaves
+        static const int k_timeout = POTRF_HANDOFF_TIMEOUT;
+        SGPR_HIP(hipMemcpyAsync(c.dinfo, &k_timeout, sizeof(int), hipMemcpyHostToDevice, su));
+    }
     EventSet es;
     if ((rc = es.create(3))) return rc;
     const int tn = n / cholq::TN;
@@ -1245,6 +1303,7 @@ int release_streams(int dev)
         }
         qd.ncu = 0;
         qd.failed = false;
+        for (int r = 0; r < 4; ++r) qd.overlap_ok[r] = false;
     }
     if (cur != dev) (void)hipSetDevice(cur);
     SGPR_HIP(first);

@@ -102,6 +102,8 @@ void remember(const Ws &w, int n, int ntasks);
 void remember_plan(const Plan *p);
 int postmortem(bool always);
 int *abort_word(const Ws &w);
+bool forced_giveup();                      // tests only: see force_giveup
+void force_giveup(int on);                 // tests only (libsympgpr_probe.so): the next queue factorisations give up at once
 
 // diagnostics (libsympgpr_probe.so): per-task time stamps of the next factorisation(s) in this process
 void set_trace(unsigned long long *dev_buf, size_t capacity_tasks);

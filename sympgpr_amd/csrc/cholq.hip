@@ -9,6 +9,7 @@
 // making progress beside them (panel kernels on the CUs this grid leaves free, chol.hip); every spin is bounded
 // and an abort word stops the whole grid when one of them runs out.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -31,20 +32,16 @@ int env_int(const char *name, int dflt)
 }
 int q_min() { static const int v = env_int("SGPR_Q_MIN", 13312); return v; }
 int q_max() { static const int v = std::min(env_int("SGPR_Q_MAX", 28672), MAX_ORDER); return v; }
-// ON by default (SGPR_POTRF_Q=0 switches it off) for SGPR_Q_MIN <= n <= SGPR_Q_MAX, where it beats the look-ahead driver by
-// 2 - 6 % (n = 16384: 30.2 vs 32.2 ms; below 13312 and above 28672 it does not).  A persistent grid that fills every CU can
-// lose workgroups for a while when the platform switches the queues out and in; the workers notice
-// (nothing published anywhere for 3 ms), drain their kernel instance and the next instance carries on (Q_INSTANCES).
-// ... and off under a profiler's counter collection (rocprofv3 --pmc / -i sets ROCPROF_COUNTER_COLLECTION): counters are
-// collected with the dispatches serialised, and the worker grid and the panel kernel have to run side by side -- the
-// look-ahead driver is profiled instead (measured: the queue path ends in its 20 s bound there).
+// ON by default (SGPR_POTRF_Q=0 switches it off) for SGPR_Q_MIN <= n <= SGPR_Q_MAX, where it beats the look-ahead driver.
+// A persistent grid that fills every CU can lose workgroups for a while when the platform switches the queues out and in
+// (DESIGN.md section 3.9); the workers notice (nothing published anywhere for 3 ms), drain their kernel instance and the next
+// instance carries on (Q_INSTANCES).  Whether the worker grid and the panel kernel CAN run side by side on this process's
+// streams is not guessed from the environment any more (round 3 looked for a profiler's ROCPROF_COUNTER_COLLECTION): chol.hip
+// tries it once per device with a pair of handshake kernels (queue_overlap_ok) -- counter collection, HIP_LAUNCH_BLOCKING,
+// AMD_SERIALIZE_KERNEL, a debugger: whatever serialises dispatches fails that test and the look-ahead driver is used.
 bool q_on()
 {
-    static const int v = [] {
-        if (!env_int("SGPR_POTRF_Q", 1)) return 0;
-        const char *cc = getenv("ROCPROF_COUNTER_COLLECTION");
-        return (cc && cc[0] && cc[0] != '0' && cc[0] != 'F' && cc[0] != 'f') ? 0 : 1;
-    }();
+    static const int v = env_int("SGPR_POTRF_Q", 1);
     return v != 0;
 }
 
@@ -483,7 +480,10 @@ struct QArgs {
 };
 
 constexpr int QT = 512;
-constexpr unsigned long long Q_WAIT_LIMIT = 20ull * 100000000ull;     // 20 s of the 100 MHz real-time counter
+constexpr unsigned long long Q_WAIT_LIMIT = 3ull * 100000000ull;      // 3 s of the 100 MHz real-time counter (round 3: 20 s).  Every earlier
+                                                                       // instance has drained after 3 ms without progress; the last one waits this long for a
+                                                                       // panel side that is kept off its CUs, then gives up -- and the caller factors again
+                                                                       // with the look-ahead driver (capi.hip)
 constexpr unsigned long long Q_GIVEUP_TICKS = 300000ull;               // 3 ms without any publish anywhere: drain this instance
 
 // is the task behind a ticket already done?  (after a rewind the head passes over tasks that were finished out of order)
@@ -527,33 +527,17 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
         a.census[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
-    int t = sh[0];
-    while (t < a.ntasks) {
-        const unsigned tk = a.tasks[2 * (size_t)t], tk1 = a.tasks[2 * (size_t)t + 1];
-        // this instance is being drained (Q_DRAIN), or the task was finished before a rewind: nothing to do for this ticket
-        if (tid == 0) {
-            const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh[2] = dr ? 2 : (task_done(a.ver, a.tver, a.tn, a.pstart, tk, tk1) ? 1 : 0);
-            if (sh[2] == 1) sh[0] = atomicAdd(a.qs, 1);
-        }
-        __syncthreads();
-        const int skip = sh[2];
-        const int tskip = sh[0];
-        __syncthreads();
-        if (skip == 2) break;
-        if (skip == 1) { t = tskip; continue; }
+    const int first_ticket = sh[0];
+    __syncthreads();
+    // ---- are the inputs of a task there?  One lane per word, relaxed polls, then ONE agent-scope acquire for the workgroup.
+    // blocking: waits (bounded; may end in a drain or a give-up).  Not blocking: ONE look.
+    // returns 1 ready, 0 given up, 2 this instance is draining, 3 not ready (not blocking only)
+    auto inputs = [&](int t, unsigned tk, unsigned tk1, bool blocking) -> int {
         const int type = (int)(tk >> 30), k = (int)((tk >> 21) & 511u), i = (int)((tk >> 11) & 1023u), j = (int)(tk & 2047u);
-        // update: leaf columns [ca, cb) of L; solve: panel k = columns [s0, s0 + w)
         const int ca = (int)(tk1 >> 16), cb = (int)(tk1 & 0xffffu);
         const int s0 = (type == TASK_T) ? a.pstart[k] : ca * LEAF;
         const int w = (type == TASK_T) ? a.pstart[k + 1] - s0 : (cb - ca) * LEAF;
         const int W = w / LEAF, j0 = s0 / TN;
-        const bool tr = a.trace != nullptr && tid == 0;
-        if (tr) a.trace[8 * (size_t)t] = __builtin_amdgcn_s_memrealtime();
-        // the ticket after this one is drawn now and used at the bottom: its round trip hides under the task
-        int tnext = 0;
-        if (tid == 0) tnext = atomicAdd(a.qs, 1);
-        // ---- inputs ready?  One lane per word, relaxed polls, then ONE agent-scope acquire for the workgroup
         if (tid < 64) {
             const int *p = nullptr;
             int need = 0;
@@ -575,6 +559,12 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             for (;;) {
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 if (__all(v >= need)) break;
+                if (!blocking) {
+                    const int ab = __hip_atomic_load((gint *)(a.qs + Q_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ab ? 0 : (dr ? 2 : 3);
+                    break;
+                }
                 // Back off, but not far: the pause grows from 0.2 us to ~7 us (SGPR_Q_POLLCAP x 3.4 us).  Round 3 first let it
                 // grow to 27 us, in the belief that hundreds of pollers starve the loads of the workgroups they wait for -- the
                 // stalls that suggested it were workgroups that had been switched out; the longer pause cost 1 - 2 %.
@@ -583,8 +573,8 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 if (reps == 0u) __builtin_amdgcn_s_sleep(8 << 2);
                 for (unsigned r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(127);
                 if (spins < 5u) continue;
-                // give up when somebody else has, or after 20 s of REAL time (a bound counted in polls would depend on how the
-                // polls are spaced, and a wave can stand still for a while without any fault of the program)
+                // give up when somebody else has, or after Q_WAIT_LIMIT of REAL time (a bound counted in polls would depend on
+                // how the polls are spaced, and a wave can stand still for a while without any fault of the program)
                 const int ab = __hip_atomic_load((gint *)(a.qs + Q_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
                 timed_out = tnow - twait0 > Q_WAIT_LIMIT;
@@ -600,8 +590,10 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 }
                 if (dr) { ok = 2; break; }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (ok == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             if (ok == 0 && timed_out) {
                 // post-mortem (sgpr_probe_queue_postmortem): the first task that gave up, and which of its words were short
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
@@ -619,8 +611,90 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             }
         }
         __syncthreads();
-        if (sh[1] != 1) break;                   // workgroup-uniform: given up (0), or this instance is draining (2: the ticket stays undone)
-        if (tr) a.trace[8 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+        const int r = sh[1];
+        __syncthreads();
+        return r;
+    };
+    // ---- the ticket loop.  Tickets are drawn in list order, but a task whose inputs are not there yet does not hold the
+    // workgroup up: it is PARKED (up to ND of them, re-examined oldest first before anything new is drawn) and the next ticket
+    // is drawn.  (Round 3's workers waited for every task in ticket order: 19 % of their time, tools/queue_trace.py -- the
+    // plan is made on a model, and what is next in the model is not always what is next on the chip.)  Forward progress as
+    // before: the inputs of a task come from smaller tickets, a workgroup only ever BLOCKS on the smallest ticket it holds,
+    // so the smallest unfinished ticket of the grid can always run.  A drained instance leaves its parked tickets undone; the
+    // rewind finds them.
+    constexpr int ND = 3;
+    int park[ND] = {0, 0, 0};
+    int npark = 0;
+    int cand = first_ticket;                     // the ticket drawn last and not yet looked at (>= ntasks: the list is exhausted)
+    for (;;) {
+        int t = -1;
+        // (a) a parked task whose inputs have arrived, oldest first
+        for (int q = 0; q < npark && t < 0; ++q) {
+            const int st = inputs(park[q], a.tasks[2 * (size_t)park[q]], a.tasks[2 * (size_t)park[q] + 1], false);
+            if (st == 0 || st == 2) return;      // given up / draining: this ticket stays undone
+            if (st == 1) {
+                t = park[q];
+                for (int r = q; r + 1 < npark; ++r) park[r] = park[r + 1];
+                --npark;
+            }
+        }
+        bool consumed = false;                   // the candidate ticket is used up: draw the next one under the task
+        if (t < 0) {
+            if (cand < a.ntasks) {
+                const unsigned ck = a.tasks[2 * (size_t)cand], ck1 = a.tasks[2 * (size_t)cand + 1];
+                // this instance is being drained (Q_DRAIN), or the task was finished before a rewind: nothing to do for this ticket
+                if (tid == 0) {
+                    const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh[2] = dr ? 2 : (task_done(a.ver, a.tver, a.tn, a.pstart, ck, ck1) ? 1 : 0);
+                    if (sh[2] == 1) sh[0] = atomicAdd(a.qs, 1);
+                }
+                __syncthreads();
+                const int skip = sh[2];
+                const int tskip = sh[0];
+                __syncthreads();
+                if (skip == 2) return;
+                if (skip == 1) { cand = tskip; continue; }
+                if (npark < ND) {
+                    const int st = inputs(cand, ck, ck1, false);
+                    if (st == 0 || st == 2) return;
+                    if (st == 3) {               // park it, draw the next
+                        park[npark++] = cand;
+                        if (tid == 0) sh[0] = atomicAdd(a.qs, 1);
+                        __syncthreads();
+                        cand = sh[0];
+                        __syncthreads();
+                        continue;
+                    }
+                    t = cand;
+                    consumed = true;
+                }
+            }
+            if (t < 0) {
+                // nothing that can run: wait for the oldest ticket this workgroup holds
+                if (npark == 0) {
+                    if (cand >= a.ntasks) return;                                    // the list is exhausted and nothing is parked
+                    // (ND == 0 only: not reached with ND > 0, where an unparked candidate is looked at above)
+                    return;
+                }
+                const int st = inputs(park[0], a.tasks[2 * (size_t)park[0]], a.tasks[2 * (size_t)park[0] + 1], true);
+                if (st != 1) return;
+                t = park[0];
+                for (int r = 0; r + 1 < npark; ++r) park[r] = park[r + 1];
+                --npark;
+            }
+        }
+        const unsigned tk = a.tasks[2 * (size_t)t], tk1 = a.tasks[2 * (size_t)t + 1];
+        const int type = (int)(tk >> 30), k = (int)((tk >> 21) & 511u), i = (int)((tk >> 11) & 1023u), j = (int)(tk & 2047u);
+        // update: leaf columns [ca, cb) of L; solve: panel k = columns [s0, s0 + w)
+        const int ca = (int)(tk1 >> 16), cb = (int)(tk1 & 0xffffu);
+        const int s0 = (type == TASK_T) ? a.pstart[k] : ca * LEAF;
+        const int w = (type == TASK_T) ? a.pstart[k + 1] - s0 : (cb - ca) * LEAF;
+        const int W = w / LEAF, j0 = s0 / TN;
+        const bool tr = a.trace != nullptr && tid == 0;
+        if (tr) { a.trace[8 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); a.trace[8 * (size_t)t + 1] = a.trace[8 * (size_t)t]; }
+        // the ticket after the candidate is drawn now and used at the bottom: its round trip hides under the task
+        int tnext = cand;
+        if (consumed && tid == 0) tnext = atomicAdd(a.qs, 1);
         // ---- the task's products (one call site of the k-loop body)
         const int nprod = (type == TASK_U) ? 1 : 2 * W - 1;
         for (int p = 0; p < nprod; ++p) {
@@ -680,15 +754,23 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             sh[0] = tnext;
         }
         __syncthreads();
-        t = sh[0];
+        cand = sh[0];
+        __syncthreads();
     }
 }
 
 }  // namespace
 
+static std::atomic<int> g_force_giveup{0};
+void force_giveup(int on) { g_force_giveup.store(on); }
+bool forced_giveup() { return g_force_giveup.load() != 0; }
+
 int prepare(const Plan &p, const Ws &w, hipStream_t st)
 {
     SGPR_HIP(hipMemsetAsync(w.qs, 0, w.zero_bytes, st));
+    // tests only (sgpr_probe_queue_force_giveup): the give-up word is raised before anybody runs -- every worker and panel
+    // strip leaves at its first wait, the factorisation ends unfinished, exactly as after a hand-off that timed out
+    if (g_force_giveup.load()) SGPR_HIP(hipMemsetAsync(w.qs + Q_ABORT, 1, sizeof(int), st));
     SGPR_HIP(hipMemcpyAsync(w.pstart, p.pinned, (size_t)(p.nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     SGPR_HIP(hipMemcpyAsync(w.tasks, p.pinned + p.nblk + 1, p.tasks.size() * sizeof(unsigned), hipMemcpyHostToDevice, st));   // two words per task
     return 0;

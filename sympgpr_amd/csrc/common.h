@@ -105,6 +105,7 @@ int potrf_batch(int nbatch, int npad, double *A, size_t stride_a, size_t lda, do
 // one panel (columns k0 .. k0 + 128 Wd, rows down to npad) of every problem; flags: potrf_batch_flag_bytes(nbatch) bytes per call
 int potrf_batch_panel(int nbatch, int npad, int k0, int Wd, double *A, size_t stride_a, size_t lda, double *inv, size_t stride_inv,
                       int *flags, int *info, hipStream_t st);
+bool potrf_queue_mark_failed(hipStream_t st);   // a queue factorisation gave up: the look-ahead driver from now on (true: the queue was in use)
 int release_device_streams(int dev);   // drain + destroy the streams potrf created on `dev` (they come back on demand)
 int trsm_rlt(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work,
              hipStream_t st);

@@ -52,6 +52,25 @@ def _count_le(K, p, nproc):
     return 0 if K < p else (K - p) // nproc + 1
 
 
+def hbm_plan(N, d, nb, world, rank=0):
+    """Bytes of HBM rank `rank` of `world` needs for N points, d pairs per point, block size nb: the local piece of Ky, the
+    two sets of panel operand buffers, the diagonal block + factor workspace, the replicated vectors.  Pure arithmetic
+    (the same bookkeeping as DistFit.__init__ / _buffers), so that a run can be refused BEFORE anything is allocated."""
+    pr, pc = grid_shape(world)
+    pi, pj = rank % pr, rank // pr
+    n = 2 * d * N
+    nbk = n // nb
+    rows, cols = len(range(pi, nbk, pr)), len(range(pj, nbk, pc))
+    per_q = [len([J for J in range(pj, nbk, pc) if J % pr == q]) for q in range(pr)]
+    blocks = 2 * (max(rows, 1) + max(cols, 1) + sum(max(c, 1) for c in per_q))
+    leaves = (nb + 127) // 128
+    work = leaves * 128 * 128 * 8 + 4 * leaves * 296 + 2 * nb * 8 + (2 << 20)      # inverses, hand-off words, solve vectors, slack
+    out = {"matrix": 8 * rows * nb * cols * nb, "panel_buffers": 8 * blocks * nb * nb,
+           "diag_block_and_workspace": 8 * nb * nb + 2 * work, "vectors": 8 * 6 * n}
+    out["total"] = sum(out.values())
+    return out
+
+
 class HipOps:
     """Block operations on torch CUDA tensors through libsympgpr_hip.so (device pointers)."""
 
@@ -135,6 +154,9 @@ class HipOps:
     def sync(self):
         torch.cuda.synchronize(self.device)
 
+    def mem_free(self):
+        return torch.cuda.mem_get_info(self.device)[0]
+
     def side(self):
         """Context of a second HIP stream: the column exchange of panel K+1 is packed and issued there,
         behind the row broadcast it depends on, while this stream runs the bulk of update K."""
@@ -154,9 +176,14 @@ class DistFit:
 
     _BIG = 1 << 60
 
-    def __init__(self, ops, family, x, y, z, hyp, sig2n, nb=1024, group=None, X=None):
+    def __init__(self, ops, family, x, y, z, hyp, sig2n, nb=1024, group=None, X=None, serial=None):
         """x, y: the (q, P) coordinates of the reference's one-pair layout; or X (N x 2d) for d
-        canonical pairs per point (then x, y are ignored and hyp = (lq.., lP.., sig))."""
+        canonical pairs per point (then x, y are ignored and hyp = (lq.., lP.., sig)).
+        serial (default: SGPR_DIST_SERIAL=1 in the environment): every collective is issued BLOCKING on the compute stream --
+        no side stream, no asynchronous handles, one collective in flight at a time -- for telling an RCCL-only failure of
+        the overlapped form from a logic error in one run."""
+        import os
+        self.serial = (os.environ.get("SGPR_DIST_SERIAL", "0") not in ("", "0")) if serial is None else bool(serial)
         self.ops, self.family = ops, family
         self.X = None if X is None else np.asfortranarray(X, dtype=np.float64)
         self.d = 1 if X is None else self.X.shape[1] // 2
@@ -183,6 +210,15 @@ class DistFit:
         self.mloc, self.nloc = len(self.rows) * nb, len(self.cols) * nb
         self.x = np.asarray(x, dtype=np.float64)
         self.y = np.asarray(y, dtype=np.float64)
+        # HBM plan of this rank against what the device has free, BEFORE the first allocation (a rank that dies in hipMalloc
+        # half way through leaves the others in a collective)
+        self.plan = hbm_plan(self.N, self.d, nb, self.world, self.rank)
+        if hasattr(ops, "mem_free"):
+            free = ops.mem_free()
+            if self.plan["total"] > free:
+                raise MemoryError("rank %d of %d: n = %d in %d x %d blocks on a %d x %d grid needs %.1f GB of HBM here (%s), %.1f GB are free"
+                                  % (self.rank, self.world, self.n, nb, nb, self.pr, self.pc, self.plan["total"] / 1e9,
+                                     ", ".join("%s %.1f" % (k, v / 1e9) for k, v in self.plan.items() if k != "total"), free / 1e9))
         self.z = torch.as_tensor(np.asarray(z, dtype=np.float64)).to(ops.device)
         # local matrix, column-major (mloc x nloc), as a flat tensor
         self.A = ops.empty(self.mloc * self.nloc)
@@ -213,6 +249,29 @@ class DistFit:
 
     def grank(self, pi, pj):
         return pi + pj * self.pr
+
+    def describe(self, steps=2):
+        """What this rank will do, as data: its communicators and, for the first `steps` panel steps, the collectives it
+        issues in issue order -- (step K, communicator, root (global rank), doubles, blocking?, stream).  Every member of a
+        communicator derives the same sub-sequence for it (issue order); bench.py prints it per rank at start-up."""
+        pr, pc, pi, pj, nb = self.pr, self.pc, self.pi, self.pj, self.nb
+        out = {"rank": self.rank, "world": self.world, "grid": [pr, pc], "coords": [pi, pj], "block": nb, "blocks": self.nbk,
+               "serial": self.serial,
+               "row_communicator": [self.grank(pi, c) for c in range(pc)], "col_communicator": [self.grank(q, pj) for q in range(pr)],
+               "hbm_plan_gb": {k: round(v / 1e9, 3) for k, v in self.plan.items()}, "steps": []}
+        for K in range(min(steps, self.nbk)):
+            kI, kJ = K % pr, K % pc
+            seq = []
+            if pj == kJ and pr > 1:
+                seq.append(("col", self.grank(kI, kJ), nb * nb + self.inv_size, True, "compute"))
+            nrow_blk = len(self.rows) - _count_le(K, pi, pr)
+            if nrow_blk > 0 and pc > 1:
+                seq.append(("row", self.grank(pi, kJ), nrow_blk * nb * nb, self.serial, "compute"))
+            if pr > 1:
+                for (q, _t, _p, cnt, _pos0, _ps) in self._col_plan(K)[2]:
+                    seq.append(("col", self.grank(q, pj), cnt * nb * nb, self.serial, "compute" if (self.serial or K == 0) else "side"))
+            out["steps"].append({"K": K, "collectives": seq})
+        return out
 
     # ------------------------------------------------------------------ Gram build (no comm)
     def build(self):
@@ -326,7 +385,9 @@ class DistFit:
             if pj == kJ:
                 Lrow.view(nb, nrow_blk * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, li0 * nb:])
             if pc > 1:
-                handles.append(dist.broadcast(Lrow, src=self.grank(pi, kJ), group=self.row_groups[pi], async_op=True))
+                h = dist.broadcast(Lrow, src=self.grank(pi, kJ), group=self.row_groups[pi], async_op=not self.serial)
+                if not self.serial:
+                    handles.append(h)
                 self.comm_bytes += 8 * Lrow.numel() * (pj != kJ)
         return (Lrow, nrow_blk, li0), handles
 
@@ -365,7 +426,9 @@ class DistFit:
             if pi == q:
                 st.view(nb, cnt, nb).copy_(Lrow.view(nb, nrow_blk, nb)[:, pos0:pos0 + (cnt - 1) * pstep + 1:pstep, :])
             if pr > 1:
-                handles.append(dist.broadcast(st, src=self.grank(q, self.pj), group=self.col_groups[self.pj], async_op=True))
+                h = dist.broadcast(st, src=self.grank(q, self.pj), group=self.col_groups[self.pj], async_op=not self.serial)
+                if not self.serial:
+                    handles.append(h)
                 self.comm_bytes += 8 * st.numel() * (pi != q)
             stages.append((st, t_q, period, cnt))
         return (lj0, ncol_blk, stages, buf), handles
@@ -422,7 +485,7 @@ class DistFit:
         self.info = 0
         self.comm_bytes = 0
         self.fail_t = torch.full((1,), self._BIG, dtype=torch.int64, device=self.info_t.device)
-        side = getattr(self.ops, "side", None)
+        side = None if self.serial else getattr(self.ops, "side", None)      # serial: everything on the compute stream
         opnd = self._exchange(0)
         for K in range(self.nbk):
             if K + 1 < self.nbk:

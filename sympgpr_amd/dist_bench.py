@@ -28,6 +28,11 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
         X, z, hyp, s2 = synth_pairs(n_pts, d)
         fit = DistFit(ops, args.family, None, None, z, hyp, s2, nb=nb, X=X)
     nb = fit.nb      # the driver may have picked a smaller block size that divides N
+    # every rank says what it is about to do before the first collective (stderr, one JSON line): its communicators, its HBM plan,
+    # the collectives of the first panel steps in issue order -- if a run stops in RCCL, this is what the ranks disagree on
+    import sys
+    sys.stderr.write("sympgpr dist plan: " + json.dumps(fit.describe(2)) + "\n")
+    sys.stderr.flush()
 
     def barrier():
         dist.barrier()

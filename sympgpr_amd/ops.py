@@ -7,36 +7,45 @@ import numpy as np
 
 from . import _lib as L
 
-_DEFAULT_FAMILY = "A"
-_tls = threading.local()      # the selection belongs to the calling thread: two threads fitting different examples
+_family = "A"                 # process-wide, like the compiled `kernels` module of the reference: set_family() changes it for everybody
+_tls = threading.local()      # family_scope() shadows it for the CALLING thread only: two threads fitting different examples
                               # (a Henon-Heiles fit beside a tokamak fit) must not flip each other's kernels
 
 
 def set_family(fam):
     """Select which generated kernels file of the reference is mirrored (default "A":
     periodic x SE, python/05_tokamak/SympGPR/kernels.f90).  The reference selects it by
-    which kernels*.f90 was compiled into the `kernels` / `sympgpr` module.
-
-    The selection is per THREAD; a thread that never selected one sees the default "A"."""
+    which kernels*.f90 was compiled into the `kernels` / `sympgpr` module -- process-wide, and so is this:
+    a selection made in the main thread is what an optimiser's worker threads see.  Inside a
+    ``family_scope`` of the calling thread it changes that scope's selection instead."""
+    global _family
     if fam not in L.FAMILIES:
         raise ValueError("family must be one of %s" % sorted(L.FAMILIES))
-    _tls.family = fam
+    if getattr(_tls, "family", None) is not None:
+        _tls.family = fam
+    else:
+        _family = fam
 
 
 def get_family():
-    return getattr(_tls, "family", _DEFAULT_FAMILY)
+    """The calling thread's ``family_scope`` selection if it is inside one, else the process-wide selection."""
+    fam = getattr(_tls, "family", None)
+    return _family if fam is None else fam
 
 
 @contextlib.contextmanager
 def family_scope(fam):
-    """Temporarily select a kernel family (the per-example modules under sympgpr_amd/examples
-    each correspond to one kernels*.f90 of the reference)."""
-    old = get_family()
-    set_family(fam)
+    """Select a kernel family for the calling THREAD until the block ends (the per-example modules under
+    sympgpr_amd/examples each correspond to one kernels*.f90 of the reference); other threads keep seeing
+    the process-wide selection."""
+    if fam not in L.FAMILIES:
+        raise ValueError("family must be one of %s" % sorted(L.FAMILIES))
+    old = getattr(_tls, "family", None)
+    _tls.family = fam
     try:
         yield
     finally:
-        set_family(old)
+        _tls.family = old
 
 
 def _check_inout(K, shape):

@@ -192,33 +192,43 @@ def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):
     assert "sympgpr_amd._lib" not in set(sys.modules) - before      # the product library was not even loaded
 
 
-def test_family_selection_is_per_thread():
-    """func.set_family / ops.family_scope select the mirrored kernels*.f90 for the CALLING thread only: a thread that
-    never selected one sees "A", and a scope in one thread does not leak into another."""
+def test_family_selection_process_default_and_thread_scope():
+    """func.set_family selects the mirrored kernels*.f90 PROCESS-wide, as the reference's compiled module does: a selection made in
+    the main thread is what a new thread sees (an optimiser's callback pool).  ops.family_scope shadows it for the calling thread
+    only: a scope in one thread does not leak into another, and set_family inside a scope stays inside it."""
     import threading
     from sympgpr_amd import func, ops
     seen = {}
     ready, go = threading.Event(), threading.Event()
 
     def other():
-        seen["fresh"] = ops.get_family()
-        func.set_family("C")
-        ready.set()
-        go.wait(10)
+        seen["fresh"] = ops.get_family()               # the main thread's process-wide "C", not a hard-wired default
+        with ops.family_scope("D"):
+            ready.set()
+            go.wait(10)
+            seen["scoped"] = func.get_family()
         seen["after"] = func.get_family()
 
-    func.set_family("A")
-    with ops.family_scope("B"):
-        t = threading.Thread(target=other)
-        t.start()
-        assert ready.wait(10)
-        assert ops.get_family() == "B"          # the other thread's "C" did not land here
-        go.set()
-        t.join()
-    assert ops.get_family() == "A"
-    assert seen == {"fresh": "A", "after": "C"}
-    with pytest.raises(ValueError):
-        func.set_family("Z")
+    func.set_family("C")
+    try:
+        with ops.family_scope("B"):
+            t = threading.Thread(target=other)
+            t.start()
+            assert ready.wait(10)
+            assert ops.get_family() == "B"              # the other thread's scope "D" did not land here
+            func.set_family("A")                        # inside a scope: changes the scope, not the process default
+            assert ops.get_family() == "A"
+            go.set()
+            t.join()
+        assert ops.get_family() == "C"
+        assert seen == {"fresh": "C", "scoped": "D", "after": "C"}
+        with pytest.raises(ValueError):
+            func.set_family("Z")
+        with pytest.raises(ValueError):
+            with ops.family_scope("Z"):
+                pass
+    finally:
+        func.set_family("A")
 
 
 def test_family_table_and_period_parameter():

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, N, nb, fam, singular, out):
+def _worker(rank, world, port, N, nb, fam, singular, out, serial=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["SYMPGPR_NO_TORCH_PRELOAD"] = "1"
@@ -37,12 +37,13 @@ def _worker(rank, world, port, N, nb, fam, singular, out):
         if singular:
             # sig < 0 flips the sign of K: Ky is indefinite and a pivot turns negative early
             hyp, s2 = [l, l, -4.0], 2.0 / l**2
-        f = DistFit(RefOps(), fam, q, P, z, hyp, s2, nb=nb)
+        f = DistFit(RefOps(), fam, q, P, z, hyp, s2, nb=nb, serial=serial)
+        desc = f.describe(3)
         f.build()
         info = f.factor()
         if info == 0:
             a = f.solve().numpy().copy()
-            out[rank] = (0, a, f.nll)
+            out[rank] = (0, a, f.nll, desc)
         else:
             out[rank] = (info, None, None)
     finally:
@@ -105,7 +106,7 @@ def test_block_cyclic_fit_matches_oracle(oracle, world, N, nb):
     a_o, nll_o, _ = oracle.fit("A", q, P, z, [l, l, 1.0], 1e-2 / l**2)
     assert len(res) == world
     for r in range(world):
-        info, a, nll = res[r]
+        info, a, nll = res[r][:3]
         assert info == 0
         assert np.linalg.norm(a - a_o) / np.linalg.norm(a_o) < 1e-11
         assert nll == pytest.approx(nll_o, rel=1e-11)
@@ -192,3 +193,50 @@ def test_sections_are_replicas_only(oracle, world, nph):
     for m in range(nph):
         a, nll, _ = oracle.fit("A", xtrain[:Np, m], xtrain[Np:, m], ztrain[:, m], hyp[m], 1e-3)
         assert np.array_equal(a0[m], a) and n0[m] == nll
+
+
+@pytest.mark.parametrize("world,N,nb", [(2, 24, 4), (4, 48, 8), (8, 64, 8)])
+def test_serial_mode_blocking_collectives(oracle, world, N, nb):
+    """SGPR_DIST_SERIAL / serial=True: every collective blocking on the compute stream, no side stream, no handles -- the form
+    to bisect an RCCL-only failure with.  Same result as the overlapped form; and what every rank says it will do (describe())
+    is consistent across the members of each communicator: same roots, same sizes, same order."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, N, nb, "A", False, out, True), nprocs=world, join=True)
+        res = dict(out)
+    rng = np.random.default_rng(1234)
+    q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+    l = 2.0 * np.sqrt(12 * np.pi / N)
+    a_o, nll_o, _ = oracle.fit("A", q, P, z, [l, l, 1.0], 1e-2 / l**2)
+    for r in range(world):
+        info, a, nll, desc = res[r]
+        assert info == 0 and np.linalg.norm(a - a_o) <= 1e-10 * np.linalg.norm(a_o) and abs(nll - nll_o) <= 1e-10 * abs(nll_o)
+        assert desc["serial"] is True and all(c[3] for st in desc["steps"] for c in st["collectives"])      # all blocking
+        assert all(c[4] == "compute" for st in desc["steps"] for c in st["collectives"])
+    # per communicator, every member lists the same (root, size) sequence per step
+    for r in range(world):
+        d = res[r][3]
+        for comm in ("row", "col"):
+            for peer in d[comm + "_communicator"]:
+                dp = res[peer][3]
+                for sa, sb in zip(d["steps"], dp["steps"]):
+                    mine = [(c[1], c[2]) for c in sa["collectives"] if c[0] == comm]
+                    theirs = [(c[1], c[2]) for c in sb["collectives"] if c[0] == comm]
+                    assert mine == theirs, (r, peer, comm, sa["K"], mine, theirs)
+
+
+def test_hbm_plan_of_the_multi_gpu_headline():
+    """BASELINE's "synthetic d=2 N=65536" (n = 262144, 550 GB) on 4 and 8 MI355X: every rank's plan -- local piece of Ky, two
+    sets of panel buffers, diagonal block + workspace -- fits 288 GB with room to spare, on 2 ranks it does not; the plan's
+    matrix bytes add up to 8 n^2 over the grid."""
+    from sympgpr_amd.dist import hbm_plan
+    N, d, nb = 65536, 2, 2048
+    n = 2 * d * N
+    for world, limit in ((8, 100e9), (4, 170e9)):
+        plans = [hbm_plan(N, d, nb, world, r) for r in range(world)]
+        assert sum(p["matrix"] for p in plans) == 8 * n * n
+        assert max(p["total"] for p in plans) < limit < 288e9, (world, max(p["total"] for p in plans) / 1e9)
+        assert all(p["panel_buffers"] < 0.2 * p["matrix"] for p in plans)
+    assert hbm_plan(N, d, nb, 2, 0)["total"] > 270e9          # 275 GB of matrix alone: not on two
+    assert hbm_plan(65536, 1, 2048, 1, 0)["matrix"] == 8 * 131072**2
