@@ -1161,19 +1161,6 @@ int queue_streams(QueueDevice &qd, int dev, int R, hipStream_t *sw, hipStream_t 
     return 0;
 }
 
-// A queue factorisation on `st`'s device has given up (POTRF_HANDOFF_TIMEOUT read back by the caller): no further one is
-// started there until the streams are released.  Returns true when the queue was in use (a retry will take the other driver).
-bool potrf_queue_mark_failed(hipStream_t st)
-{
-    int dev = -1;
-    if ((st ? hipStreamGetDevice(st, &dev) : hipGetDevice(&dev)) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
-    QueueDevice &qd = g_qdev[dev];
-    std::lock_guard<std::mutex> lock(qd.mu);
-    const bool was_on = !qd.failed;
-    qd.failed = true;
-    return was_on;
-}
-
 // returns 1 when the queue form cannot be used here (the caller falls back to the look-ahead driver), < 0 on errors
 int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
 {
@@ -1511,6 +1498,19 @@ int potrf_batch_panel(int nbatch, int npad, int k0, int Wd, double *A, size_t st
     hipLaunchKernelGGL(panel_batch_kernel, dim3((unsigned)(nbatch * R)), dim3(LT), 0, st, q);
     SGPR_CHECK_LAUNCH();
     return 0;
+}
+
+// A queue factorisation on `st`'s device has given up (POTRF_HANDOFF_TIMEOUT read back by the caller): no further one is
+// started there until the streams are released.  Returns true when the queue was in use (a retry will take the other driver).
+bool potrf_queue_mark_failed(hipStream_t st)
+{
+    int dev = -1;
+    if ((st ? hipStreamGetDevice(st, &dev) : hipGetDevice(&dev)) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
+    QueueDevice &qd = g_qdev[dev];
+    std::lock_guard<std::mutex> lock(qd.mu);
+    const bool was_on = !qd.failed;
+    qd.failed = true;
+    return was_on;
 }
 
 int release_device_streams(int dev)

@@ -527,17 +527,39 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
         a.census[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
     __syncthreads();
-    const int first_ticket = sh[0];
-    __syncthreads();
-    // ---- are the inputs of a task there?  One lane per word, relaxed polls, then ONE agent-scope acquire for the workgroup.
-    // blocking: waits (bounded; may end in a drain or a give-up).  Not blocking: ONE look.
-    // returns 1 ready, 0 given up, 2 this instance is draining, 3 not ready (not blocking only)
-    auto inputs = [&](int t, unsigned tk, unsigned tk1, bool blocking) -> int {
+    int t = sh[0];
+    __syncthreads();                             // (sh[0] is written again below, by one lane, possibly before a slow wave has read it)
+    // Tickets are worked in list order, and a workgroup WAITS for the task it has drawn.  Tried in round 4: parking a task whose
+    // inputs are not there yet (up to three per workgroup, re-examined oldest first) and drawing on -- n = 16384: 27.7 ms in
+    // strict order, 27.9 - 28.7 with one parked task after 30 - 300 us of patience, 32 - 33 with two, 45 without patience.  The
+    // list order IS the priority order: a worker that helps itself to a long bulk update while the task next to the chain is
+    // 20 us from being ready costs the chain 400.
+    while (t < a.ntasks) {
+        const unsigned tk = a.tasks[2 * (size_t)t], tk1 = a.tasks[2 * (size_t)t + 1];
+        // this instance is being drained (Q_DRAIN), or the task was finished before a rewind: nothing to do for this ticket
+        if (tid == 0) {
+            const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh[2] = dr ? 2 : (task_done(a.ver, a.tver, a.tn, a.pstart, tk, tk1) ? 1 : 0);
+            if (sh[2] == 1) sh[0] = atomicAdd(a.qs, 1);
+        }
+        __syncthreads();
+        const int skip = sh[2];
+        const int tskip = sh[0];
+        __syncthreads();
+        if (skip == 2) break;
+        if (skip == 1) { t = tskip; continue; }
         const int type = (int)(tk >> 30), k = (int)((tk >> 21) & 511u), i = (int)((tk >> 11) & 1023u), j = (int)(tk & 2047u);
+        // update: leaf columns [ca, cb) of L; solve: panel k = columns [s0, s0 + w)
         const int ca = (int)(tk1 >> 16), cb = (int)(tk1 & 0xffffu);
         const int s0 = (type == TASK_T) ? a.pstart[k] : ca * LEAF;
         const int w = (type == TASK_T) ? a.pstart[k + 1] - s0 : (cb - ca) * LEAF;
         const int W = w / LEAF, j0 = s0 / TN;
+        const bool tr = a.trace != nullptr && tid == 0;
+        if (tr) a.trace[8 * (size_t)t] = __builtin_amdgcn_s_memrealtime();
+        // the ticket after this one is drawn now and used at the bottom: its round trip hides under the task
+        int tnext = 0;
+        if (tid == 0) tnext = atomicAdd(a.qs, 1);
+        // ---- inputs ready?  One lane per word, relaxed polls, then ONE agent-scope acquire for the workgroup
         if (tid < 64) {
             const int *p = nullptr;
             int need = 0;
@@ -559,12 +581,6 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             for (;;) {
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 if (__all(v >= need)) break;
-                if (!blocking) {
-                    const int ab = __hip_atomic_load((gint *)(a.qs + Q_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ab ? 0 : (dr ? 2 : 3);
-                    break;
-                }
                 // Back off, but not far: the pause grows from 0.2 us to ~7 us (SGPR_Q_POLLCAP x 3.4 us).  Round 3 first let it
                 // grow to 27 us, in the belief that hundreds of pollers starve the loads of the workgroups they wait for -- the
                 // stalls that suggested it were workgroups that had been switched out; the longer pause cost 1 - 2 %.
@@ -573,8 +589,8 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 if (reps == 0u) __builtin_amdgcn_s_sleep(8 << 2);
                 for (unsigned r = 0; r < reps; ++r) __builtin_amdgcn_s_sleep(127);
                 if (spins < 5u) continue;
-                // give up when somebody else has, or after Q_WAIT_LIMIT of REAL time (a bound counted in polls would depend on
-                // how the polls are spaced, and a wave can stand still for a while without any fault of the program)
+                // give up when somebody else has, or after Q_WAIT_LIMIT of REAL time (a bound counted in polls would depend on how the
+                // polls are spaced, and a wave can stand still for a while without any fault of the program)
                 const int ab = __hip_atomic_load((gint *)(a.qs + Q_ABORT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long tnow = __builtin_amdgcn_s_memrealtime();
                 timed_out = tnow - twait0 > Q_WAIT_LIMIT;
@@ -590,10 +606,8 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
                 }
                 if (dr) { ok = 2; break; }
             }
-            if (ok == 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (ok == 0 && timed_out) {
                 // post-mortem (sgpr_probe_queue_postmortem): the first task that gave up, and which of its words were short
                 const int v = p ? __hip_atomic_load((gint *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
@@ -611,90 +625,8 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             }
         }
         __syncthreads();
-        const int r = sh[1];
-        __syncthreads();
-        return r;
-    };
-    // ---- the ticket loop.  Tickets are drawn in list order, but a task whose inputs are not there yet does not hold the
-    // workgroup up: it is PARKED (up to ND of them, re-examined oldest first before anything new is drawn) and the next ticket
-    // is drawn.  (Round 3's workers waited for every task in ticket order: 19 % of their time, tools/queue_trace.py -- the
-    // plan is made on a model, and what is next in the model is not always what is next on the chip.)  Forward progress as
-    // before: the inputs of a task come from smaller tickets, a workgroup only ever BLOCKS on the smallest ticket it holds,
-    // so the smallest unfinished ticket of the grid can always run.  A drained instance leaves its parked tickets undone; the
-    // rewind finds them.
-    constexpr int ND = 3;
-    int park[ND] = {0, 0, 0};
-    int npark = 0;
-    int cand = first_ticket;                     // the ticket drawn last and not yet looked at (>= ntasks: the list is exhausted)
-    for (;;) {
-        int t = -1;
-        // (a) a parked task whose inputs have arrived, oldest first
-        for (int q = 0; q < npark && t < 0; ++q) {
-            const int st = inputs(park[q], a.tasks[2 * (size_t)park[q]], a.tasks[2 * (size_t)park[q] + 1], false);
-            if (st == 0 || st == 2) return;      // given up / draining: this ticket stays undone
-            if (st == 1) {
-                t = park[q];
-                for (int r = q; r + 1 < npark; ++r) park[r] = park[r + 1];
-                --npark;
-            }
-        }
-        bool consumed = false;                   // the candidate ticket is used up: draw the next one under the task
-        if (t < 0) {
-            if (cand < a.ntasks) {
-                const unsigned ck = a.tasks[2 * (size_t)cand], ck1 = a.tasks[2 * (size_t)cand + 1];
-                // this instance is being drained (Q_DRAIN), or the task was finished before a rewind: nothing to do for this ticket
-                if (tid == 0) {
-                    const int dr = __hip_atomic_load((gint *)(a.qs + Q_DRAIN), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sh[2] = dr ? 2 : (task_done(a.ver, a.tver, a.tn, a.pstart, ck, ck1) ? 1 : 0);
-                    if (sh[2] == 1) sh[0] = atomicAdd(a.qs, 1);
-                }
-                __syncthreads();
-                const int skip = sh[2];
-                const int tskip = sh[0];
-                __syncthreads();
-                if (skip == 2) return;
-                if (skip == 1) { cand = tskip; continue; }
-                if (npark < ND) {
-                    const int st = inputs(cand, ck, ck1, false);
-                    if (st == 0 || st == 2) return;
-                    if (st == 3) {               // park it, draw the next
-                        park[npark++] = cand;
-                        if (tid == 0) sh[0] = atomicAdd(a.qs, 1);
-                        __syncthreads();
-                        cand = sh[0];
-                        __syncthreads();
-                        continue;
-                    }
-                    t = cand;
-                    consumed = true;
-                }
-            }
-            if (t < 0) {
-                // nothing that can run: wait for the oldest ticket this workgroup holds
-                if (npark == 0) {
-                    if (cand >= a.ntasks) return;                                    // the list is exhausted and nothing is parked
-                    // (ND == 0 only: not reached with ND > 0, where an unparked candidate is looked at above)
-                    return;
-                }
-                const int st = inputs(park[0], a.tasks[2 * (size_t)park[0]], a.tasks[2 * (size_t)park[0] + 1], true);
-                if (st != 1) return;
-                t = park[0];
-                for (int r = 0; r + 1 < npark; ++r) park[r] = park[r + 1];
-                --npark;
-            }
-        }
-        const unsigned tk = a.tasks[2 * (size_t)t], tk1 = a.tasks[2 * (size_t)t + 1];
-        const int type = (int)(tk >> 30), k = (int)((tk >> 21) & 511u), i = (int)((tk >> 11) & 1023u), j = (int)(tk & 2047u);
-        // update: leaf columns [ca, cb) of L; solve: panel k = columns [s0, s0 + w)
-        const int ca = (int)(tk1 >> 16), cb = (int)(tk1 & 0xffffu);
-        const int s0 = (type == TASK_T) ? a.pstart[k] : ca * LEAF;
-        const int w = (type == TASK_T) ? a.pstart[k + 1] - s0 : (cb - ca) * LEAF;
-        const int W = w / LEAF, j0 = s0 / TN;
-        const bool tr = a.trace != nullptr && tid == 0;
-        if (tr) { a.trace[8 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); a.trace[8 * (size_t)t + 1] = a.trace[8 * (size_t)t]; }
-        // the ticket after the candidate is drawn now and used at the bottom: its round trip hides under the task
-        int tnext = cand;
-        if (consumed && tid == 0) tnext = atomicAdd(a.qs, 1);
+        if (sh[1] != 1) break;                   // workgroup-uniform: given up (0), or this instance is draining (2: the ticket stays undone)
+        if (tr) a.trace[8 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
         // ---- the task's products (one call site of the k-loop body)
         const int nprod = (type == TASK_U) ? 1 : 2 * W - 1;
         for (int p = 0; p < nprod; ++p) {
@@ -754,8 +686,7 @@ __global__ __launch_bounds__(QT, 2) void chol_queue_kernel(const QArgs a)
             sh[0] = tnext;
         }
         __syncthreads();
-        cand = sh[0];
-        __syncthreads();
+        t = sh[0];
     }
 }
 
