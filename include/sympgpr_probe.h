@@ -66,6 +66,10 @@ int sgpr_probe_queue_postmortem(int always);
 /* TESTS ONLY: while on, every task-queue factorisation of this process gives up before it starts (the give-up word is raised and
  * the factor's info word set as by a hand-off that timed out) -- to exercise the callers' retry with the other driver */
 int sgpr_probe_queue_force_giveup(int on);
+/* the last sgpr_applymap_host of this process: K*-row evaluations (residuals of the implicit equation + q updates) summed over
+ * its orbits, and the number of workgroups that share one orbit for ntest orbits on n0 training points */
+unsigned sgpr_probe_map_calls(void);
+int sgpr_probe_map_team(int ntest, int n0);
 
 /* co-residency census of two concurrent kernels (A: na workgroups of threads_a threads with lds_a bytes of LDS spinning
  * spin_a us on one stream, B likewise on a second, high-priority stream; optional CU masks): per workgroup XCC id,

@@ -130,6 +130,8 @@ PROBE_SIGNATURES = {
     "sgpr_probe_queue_trace_end": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sgpr_probe_queue_postmortem": (C.c_int, [C.c_int]),
     "sgpr_probe_queue_force_giveup": (C.c_int, [C.c_int]),
+    "sgpr_probe_map_calls": (C.c_uint, []),
+    "sgpr_probe_map_team": (C.c_int, [C.c_int, C.c_int]),
     "sgpr_probe_queue_trace_clear": (C.c_int, []),
     "sgpr_probe_census": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,

@@ -1041,9 +1041,10 @@ int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hy
         set_error("applymap: null argument");
         return SGPR_E_ARG;
     }
-    DevBuf x, y, al, xp, yp, alp, q0, p0, qm, pm, pd;
+    DevBuf x, y, al, xp, yp, alp, q0, p0, qm, pm, pd, tw;
     hipStream_t st = nullptr;
     const size_t out_bytes = (size_t)nm * ntest * sizeof(double);
+    if ((rc = tw.alloc(applymap_team_ws(ntest, n0)))) return rc;
     if ((rc = upload(x, xtrain, n0, st)) || (rc = upload(y, ytrain, n0, st)) || (rc = upload(al, alpha, 2 * (size_t)n0, st)) ||
         (rc = upload(xp, xtrainp, n0p, st)) || (rc = upload(yp, ytrainp, n0p, st)) || (rc = upload(alp, alphap, n0p, st)) ||
         (rc = upload(q0, Q0, ntest, st)) || (rc = upload(p0, P0, ntest, st)) || (rc = qm.alloc(out_bytes)) ||
@@ -1051,13 +1052,13 @@ int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hy
         return rc;
     rc = applymap(family, mode, nm, ntest, n0, x.as<double>(), y.as<double>(), kc, al.as<double>(), n0p,
                   xp.as<double>(), yp.as<double>(), kcp, alp.as<double>(), q0.as<double>(), p0.as<double>(),
-                  qm.as<double>(), pm.as<double>(), pdiff ? pd.as<double>() : nullptr, st);
+                  qm.as<double>(), pm.as<double>(), pdiff ? pd.as<double>() : nullptr, tw.p, st);
     if (rc) return rc;
     SGPR_HIP(hipMemcpyAsync(qmap, qm.p, out_bytes, hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipMemcpyAsync(pmap, pm.p, out_bytes, hipMemcpyDeviceToHost, st));
     if (pdiff) SGPR_HIP(hipMemcpyAsync(pdiff, pd.p, out_bytes, hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipStreamSynchronize(st));
-    return 0;
+    return applymap_status(tw.p, ntest, n0);
 }
 
 int sgpr_profile_begin(void) { return gemm_profile_begin(); }

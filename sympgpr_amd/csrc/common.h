@@ -53,10 +53,14 @@ int predict_reg(int family, int m, const double *q, const double *P, int n0, con
                 const double *ytr, const KConst &kc, const double *alpha, double *out,
                 hipStream_t st);
 
+int applymap_team(int ntest, int n0);          // workgroups that share one orbit
+size_t applymap_team_ws(int ntest, int n0);    // bytes of device scratch applymap needs
 int applymap(int family, int mode, int nm, int ntest, int n0, const double *xtr, const double *ytr,
              const KConst &kc, const double *alpha, int n0p, const double *xtrp, const double *ytrp,
              const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
-             double *pmap, double *pdiff, hipStream_t st);
+             double *pmap, double *pdiff, void *team_ws, hipStream_t st);
+int applymap_status(const void *team_ws, int ntest, int n0);
+unsigned applymap_last_calls();                 // K*-row evaluations (all orbits) of the last applymap of this process   // after the stream has been waited for: SGPR_E_HIP if a team gave up
 
 // ---- gram_nd.hip : d canonical pairs per point (X: points x 2d, column-major)
 int gram_nd(int family, int d, int mi, int mj, const double *Xb, size_t ldxb, const double *Xa, size_t ldxa,

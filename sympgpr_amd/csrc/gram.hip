@@ -13,6 +13,7 @@
 //   * the 16 column points of the tile are staged once in LDS and read back as broadcasts;
 //   * sig scaling, the |sig2n| diagonal and the lower-triangle cut are fused here (the
 //     reference spends three more n^2 passes on them: sympgpr.f90:37, func.py:192).
+#include <atomic>
 #include "common.h"
 #include "devmath.h"
 #include "pair_eval.h"
@@ -307,6 +308,9 @@ __global__ __launch_bounds__(GT) void predict_reg_kernel(int n0, const double *q
 // block-wide reduction over the training points, and all nm steps run without leaving the GPU.
 struct MapArgs {
     int nm, ntest, n0, n0p, mode, maxiter;
+    int S;                                // workgroups per orbit (the team): each sums its share of the training points
+    unsigned long long *tw;               // team exchange words: [orbit][member][wave][parity][2] 16-byte granules {value, sequence}, zero on entry
+    int *err;                             // set when a team member gave up waiting for another
     double tol;
     const double *xtr, *ytr, *alpha;      // symplectic GP: n0 points, alpha 2 n0
     const double *xtrp, *ytrp, *alphap;   // regular GP (guess): n0p points
@@ -331,31 +335,94 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
     b = sh[1] + sh[3] + sh[5] + sh[7];
 }
 
+// 16-byte {value, sequence number} granules, written by one write-through store and read by one load that passes the vector L1
+// (MI355X_MICROARCH.md, inter-workgroup visibility: 16-byte sc1 halves were observed untorn): the value and the word that says
+// which residual it belongs to arrive together, so a member that finds the expected sequence number has the value.
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void granule_store(unsigned long long *p, double v, unsigned seq)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint4_t w = {(unsigned)b, (unsigned)(b >> 32), seq, 0u};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
+// both granules of a pair in flight together: one memory round trip per look
+__device__ __forceinline__ void granule_load2(const unsigned long long *p, uint4_t &u, uint4_t &v)
+{
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(u), "=&v"(v) : "v"(p) : "memory");
+}
+
+// One workgroup per (orbit, team member).  With a.S == 1 this is the round-2 kernel: one workgroup runs the whole iteration
+// of its orbit.  For large training sets (the drivers use 20 - 80 points; BASELINE config 05 has 16384) S workgroups share an
+// orbit: every residual is summed in S parts, exchanged through a.tw and added up in member order by every member alike -- all
+// members then hold the same bits, take the same branches and need no leader.  Ntest = 37 orbits no longer mean 37 CUs.
 template <int FAM>
 __global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
 {
     __shared__ double sh[8];
-    const int k = blockIdx.x;
+    __shared__ double sp[2][8 * (GT / 64)];
+    const int S = a.S, k = blockIdx.x / S, me = blockIdx.x - k * S;
+    unsigned seq = 0;
+    bool lost = false;                                  // a team member did not answer in time: the orbit is lost (NaN), a.err says why
+    // (x, y) := sum over the team of every thread's (x, y), identical bits in every member.  Every WAVE publishes its own part
+    // (no block-wide reduction in front of the exchange), lanes 0 .. 4 S - 1 of wave 0 collect them.
+    auto team_sum2 = [&](double &x, double &y) {
+        if (S == 1) { block_sum2(x, y, sh); return; }
+        for (int o = 32; o > 0; o >>= 1) {
+            x += __shfl_down(x, o, 64);
+            y += __shfl_down(y, o, 64);
+        }
+        ++seq;
+        constexpr int NW = GT / 64;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *mine = a.tw + ((((size_t)k * S + me) * NW + (threadIdx.x >> 6)) * 2 + (seq & 1u)) * 4;
+            granule_store(mine, x, seq);
+            granule_store(mine + 2, y, seq);
+        }
+        if (threadIdx.x < (unsigned)(S * NW)) {
+            const unsigned long long *theirs = a.tw + (((size_t)k * S * NW + threadIdx.x) * 2 + (seq & 1u)) * 4;
+            uint4_t u, v;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned it = 0;
+            bool ok = true;
+            for (;;) {
+                granule_load2(theirs, u, v);
+                if (u[2] == seq && v[2] == seq) break;
+                if ((++it & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { ok = false; break; }    // 2 s
+            }
+            sp[0][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)u[1] << 32) | u[0])) : __builtin_nan("");
+            sp[1][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0])) : __builtin_nan("");
+            if (!ok) atomicExch(a.err, 1);
+        }
+        __syncthreads();
+        double sx = 0.0, sy = 0.0;
+        for (int m = 0; m < S * NW; ++m) { sx += sp[0][m]; sy += sp[1][m]; }
+        x = sx; y = sy;
+        __syncthreads();
+    };
+    unsigned ncalls = 0;                                // residual evaluations of this orbit (measurement aid)
     auto rows = [&](double q, double P, double &r1, double &r2) {   // Kstar(1,:).alpha, Kstar(2,:).alpha
         r1 = 0.0; r2 = 0.0;
-        for (int j = threadIdx.x; j < a.n0; j += GT) {
+        ++ncalls;
+        for (int j = me * GT + threadIdx.x; j < a.n0; j += S * GT) {
             double kxx, kxy, kyy;
             pair_eval<FAM, false>(a.xtr[j], a.ytr[j], q, P, a.kc, kxx, kxy, kyy);
             const double a1 = a.alpha[j], a2 = a.alpha[a.n0 + j];
             r1 += kxx * a1 + kxy * a2;
             r2 += kxy * a1 + kyy * a2;
         }
-        block_sum2(r1, r2, sh);
+        team_sum2(r1, r2);
     };
     auto guess = [&](double q, double p) {
         double r = 0.0, z = 0.0;
-        for (int j = threadIdx.x; j < a.n0p; j += GT)
+        for (int j = me * GT + threadIdx.x; j < a.n0p; j += S * GT)
             r += a.kcp.sig * kern_eval<FAM, false>(a.xtrp[j], a.ytrp[j], q, p, a.kcp) * a.alphap[j];
-        block_sum2(r, z, sh);
+        team_sum2(r, z);
         return r;
     };
+    (void)lost;
     double q = a.Q0[k], p = a.P0[k], pd = p;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && me == 0) {
         a.qmap[k] = q;
         a.pmap[k] = p;
         if (a.pdiff) a.pdiff[k] = pd;
@@ -403,12 +470,13 @@ __global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
             }
         }
         q = qn; p = pn; pd = pdn;
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && me == 0) {
             a.qmap[(size_t)(i + 1) * a.ntest + k] = q;
             a.pmap[(size_t)(i + 1) * a.ntest + k] = p;
             if (a.pdiff) a.pdiff[(size_t)(i + 1) * a.ntest + k] = pd;
         }
     }
+    if (threadIdx.x == 0 && me == 0) atomicAdd((unsigned *)(a.err + 1), ncalls);
 }
 
 template <typename F>
@@ -568,19 +636,51 @@ int predict_rows(int family, int m, const double *q, const double *P, int n0, co
     });
 }
 
+// Workgroups per orbit: as many as fill the chip (256 CUs) with ntest orbits, at most 8, and no more than the training set can
+// feed with two rounds of 256 points each -- the drivers' own sizes (20 - 80 points) keep one workgroup per orbit.
+int applymap_team(int ntest, int n0)
+{
+    int S = ntest > 0 ? 256 / ntest : 1;
+    S = std::min(S, (n0 + 511) / 512);
+    return std::max(1, std::min(S, 8));
+}
+size_t applymap_team_ws(int ntest, int n0)
+{
+    return ((size_t)ntest * applymap_team(ntest, n0) * (GT / 64) * 2 * 4 + 2) * sizeof(unsigned long long);    // granules + the error word
+}
+
+// team_ws: applymap_team_ws(ntest, n0) bytes of device scratch (cleared here)
 int applymap(int family, int mode, int nm, int ntest, int n0, const double *xtr, const double *ytr,
              const KConst &kc, const double *alpha, int n0p, const double *xtrp, const double *ytrp,
              const KConst &kcp, const double *alphap, const double *Q0, const double *P0, double *qmap,
-             double *pmap, double *pdiff, hipStream_t st)
+             double *pmap, double *pdiff, void *team_ws, hipStream_t st)
 {
     if (nm <= 0 || ntest <= 0) return 0;
-    MapArgs a{nm, ntest, n0, n0p, mode, 60, 1e-13, xtr, ytr, alpha, xtrp, ytrp, alphap, Q0, P0, qmap, pmap, pdiff, kc, kcp};
+    const int S = applymap_team(ntest, n0);
+    SGPR_HIP(hipMemsetAsync(team_ws, 0, applymap_team_ws(ntest, n0), st));
+    unsigned long long *tw = static_cast<unsigned long long *>(team_ws);
+    int *err = reinterpret_cast<int *>(tw + (size_t)ntest * S * (GT / 64) * 2 * 4);
+    MapArgs a{nm, ntest, n0, n0p, mode, 60, S, tw, err, 1e-13, xtr, ytr, alpha, xtrp, ytrp, alphap, Q0, P0, qmap, pmap, pdiff, kc, kcp};
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
-        hipLaunchKernelGGL((applymap_kernel<F>), dim3(ntest), dim3(GT), 0, st, a);
+        hipLaunchKernelGGL((applymap_kernel<F>), dim3(ntest * S), dim3(GT), 0, st, a);
         SGPR_CHECK_LAUNCH();
         return 0;
     });
+}
+static std::atomic<unsigned> g_last_map_calls{0};
+unsigned applymap_last_calls() { return g_last_map_calls.load(); }    // measurement aid (libsympgpr_probe.so): K*-row evaluations of the last map
+
+// after the stream has been waited for: did a team member give up on another (never a property of the data)?
+int applymap_status(const void *team_ws, int ntest, int n0)
+{
+    const unsigned long long *tw = static_cast<const unsigned long long *>(team_ws);
+    int hh[2] = {0, 0};
+    SGPR_HIP(hipMemcpy(hh, tw + (size_t)ntest * applymap_team(ntest, n0) * (GT / 64) * 2 * 4, sizeof(hh), hipMemcpyDeviceToHost));
+    g_last_map_calls.store((unsigned)hh[1]);
+    const int h = hh[0];
+    if (h) { set_error("applymap: a workgroup of an orbit's team did not answer in time"); return SGPR_E_HIP; }
+    return 0;
 }
 
 int predict_reg(int family, int m, const double *q, const double *P, int n0, const double *xtr,

@@ -403,6 +403,8 @@ extern "C" int sgpr_probe_queue_trace_end(unsigned long long *out, int max_tasks
 
 extern "C" int sgpr_probe_queue_postmortem(int always) { return cholq::postmortem(always != 0); }
 extern "C" int sgpr_probe_queue_force_giveup(int on) { cholq::force_giveup(on); return 0; }
+extern "C" unsigned sgpr_probe_map_calls(void) { return applymap_last_calls(); }
+extern "C" int sgpr_probe_map_team(int ntest, int n0) { return applymap_team(ntest, n0); }
 
 // ---- co-residency census: where and when do the workgroups of two concurrent kernels run?
 // Kernel A (grid na, lds_a bytes of dynamic LDS, spins spin_a us) on one stream, kernel B (nb, lds_b, spin_b) on

@@ -19,6 +19,26 @@ from .ops import get_family
 WRAP_Q, WRAP_P, EXPLICIT = L.MAP_WRAP_Q, L.MAP_WRAP_P, L.MAP_EXPLICIT
 
 
+def run_map_alpha(mode, nm, Ntest, l, Q0map, P0map, xt, yt, alpha, hypp=None, xp=None, yp=None, alphap=None, family=None):
+    """The same iteration from the posterior weights themselves (alpha = Ky^-1 ztrain, 2 N0; alphap, N0p) instead of the explicit
+    inverses the drivers carry around: for training sets where Kyinv (8 (2 N0)^2 bytes) is not something to form."""
+    lib = L.load_library()
+    f = L.f64
+    family = get_family() if family is None else family
+    xt, yt, alpha, hyp = f(xt), f(yt), f(alpha), f(l)
+    if mode & EXPLICIT:
+        xp, yp, alphap, hp = f([]), f([]), f([]), f([])
+    else:
+        xp, yp, alphap, hp = f(xp), f(yp), f(alphap), f(hypp)
+    Q0, P0 = f(np.broadcast_to(Q0map, (Ntest,))), f(np.broadcast_to(P0map, (Ntest,)))
+    pmap, qmap = np.zeros([nm, Ntest]), np.zeros([nm, Ntest])
+    L.check(lib.sgpr_applymap_host(L.family_id(family), int(mode), nm, Ntest, L.dptr(hyp), len(hyp), len(xt),
+                                   L.dptr(xt), L.dptr(yt), L.dptr(alpha), L.dptr(hp), len(hp), len(xp), L.dptr(xp),
+                                   L.dptr(yp), L.dptr(alphap), L.dptr(Q0), L.dptr(P0), L.dptr(qmap), L.dptr(pmap), None),
+            "sgpr_applymap_host")
+    return qmap, pmap
+
+
 def run_map(mode, nm, Ntest, l, Q0map, P0map, xtrain, ztrain, Kyinv, hypp=None, xtrainp=None, ztrainp=None,
             Kyinvp=None, want_pdiff=False, family=None):
     """-> (qmap, pmap) or (qmap, pmap, pdiff), each [nm, Ntest].  `l` = (lx, ly, sig) of the

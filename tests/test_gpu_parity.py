@@ -458,6 +458,48 @@ def test_mirror_applymap_vs_pointwise_reference(oracle):
     np.testing.assert_allclose(np.delete(p2, 2, axis=1), np.delete(pmap[:3], 2, axis=1), rtol=1e-12)
 
 
+def test_applymap_orbit_shared_by_several_workgroups(oracle):
+    """Large training sets: the residuals of one orbit are summed by a TEAM of workgroups (3 here: 20 orbits on 1500 points) that
+    exchange their parts through memory and all take the same branches.  Against the recurrences of functions/func.py:204-237
+    written out on the host with the oracle's K*-rows and MINPACK hybrd, from posterior weights fitted on the device."""
+    import scipy.optimize
+    from sympgpr_amd import _lib as L, maps
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(21)
+    Nt, Ntest, nm = 1500, 20, 4
+    assert L.load_probe_library().sgpr_probe_map_team(Ntest, Nt) == 3
+    q, pn = rng.uniform(0, 2 * np.pi, Nt), rng.uniform(-1, 1, Nt)
+    p_old = pn + 0.3 * np.sin(q); Q = q + 0.3 * pn               # a gentle symplectic map as training data
+    ztrain = np.hstack((p_old - pn, Q - q))
+    hyp, hypp, s2 = np.array([0.9, 1.1, 1.0]), np.array([0.9, 1.1, 1.0]), 1e-6
+    with SympFit("A", q, pn, ztrain, hyp, s2) as f:
+        alpha = f.run().alpha()
+    with SympFit("A", q, p_old, pn, hypp, s2, reg=True) as f:
+        alphap = f.run().alpha()
+    Q0, P0 = rng.uniform(0.5, 5.5, Ntest), rng.uniform(-0.5, 0.5, Ntest)
+    P0[7] = np.nan                                                 # a lost orbit in the middle of the teams
+    qmap, pmap = maps.run_map_alpha(maps.WRAP_Q, nm, Ntest, hyp, Q0, P0, q, pn, alpha, hypp, q, p_old, alphap, family="A")
+    qr, pr = np.zeros((nm, Ntest)), np.zeros((nm, Ntest))
+    qr[0], pr[0] = Q0, P0
+    for i in range(nm - 1):
+        for k in range(Ntest):
+            if np.isnan(pr[i, k]):
+                qr[i + 1, k] = pr[i + 1, k] = np.nan
+                continue
+            g0 = oracle.predict_reg("A", [qr[i, k]], [pr[i, k]], q, p_old, hypp, alphap)[0]
+            fres = lambda Pn: oracle.predict_rows("A", [qr[i, k]], [Pn[0]], q, pn, hyp, alpha)[0][0] - pr[i, k] + Pn[0]
+            pr[i + 1, k] = scipy.optimize.fsolve(fres, [g0], xtol=1e-13)[0]
+            dq = oracle.predict_rows("A", [qr[i, k]], [pr[i + 1, k]], q, pn, hyp, alpha)[1][0]
+            qr[i + 1, k] = np.mod(dq + qr[i, k], 2 * np.pi)
+    ok = ~np.isnan(pr)
+    assert np.array_equal(np.isnan(pmap), np.isnan(pr)) and np.array_equal(np.isnan(qmap), np.isnan(qr))
+    np.testing.assert_allclose(pmap[ok], pr[ok], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(qmap[ok], qr[ok], rtol=1e-8, atol=1e-8)
+    # and run to run the teams reproduce themselves bit for bit (every member adds the parts in member order)
+    q2, p2 = maps.run_map_alpha(maps.WRAP_Q, nm, Ntest, hyp, Q0, P0, q, pn, alpha, hypp, q, p_old, alphap, family="A")
+    assert np.array_equal(q2[ok], qmap[ok]) and np.array_equal(p2[ok], pmap[ok])
+
+
 # ---------------------------------------------------------------- hyper-parameter gradients
 @pytest.mark.parametrize("fam", ["A", "B", "C", "D"])
 def test_build_dK_vs_oracle(oracle, fam):
