@@ -135,6 +135,62 @@ def load_traffic(n_pts, d, family, lower_only):
     return {}, None
 
 
+def batch_leg(args):
+    """python bench.py --batch ORDER,COUNT: COUNT independent fits of order ORDER (the body of nll_chol, python/functions/func.py:
+    189-196, per problem: Gram build, Cholesky, two solves, nll) through ONE sgpr_fit_batch call -- the reference's only batch axis
+    (05_tokamak/Split_SympGPR/main.py:36-41,63-66).  Wall time of the call (inputs from host arrays through the pinned staging
+    block, outputs back), median of the timed calls."""
+    from sympgpr_amd.fit import fit_batch
+    n, B = (int(v) for v in args.batch.split(","))
+    Np = n // 2
+    rng = np.random.default_rng(3)
+    x, y = rng.uniform(0, 2 * np.pi, (B, Np)), rng.uniform(-3, 3, (B, Np))
+    z = rng.standard_normal((B, n))
+    l = 2.0 * np.sqrt(12 * np.pi / Np)
+    hyp = np.tile([l, l, 1.0], (B, 1))
+    s2 = np.full(B, 1e-2 / l**2)
+    for _ in range(max(args.warmup, 1)):
+        fit_batch(args.family, x, y, z, hyp, s2, want_alpha=False)
+    ts = []
+    for _ in range(max(args.steps, 5)):
+        t0 = time.perf_counter()
+        _, nll, info = fit_batch(args.family, x, y, z, hyp, s2, want_alpha=False)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    flop_fit = n**3 / 3.0 + 2.0 * n * n            # factor + the two triangular solves (the Gram build is not flop on the matrix cores)
+    out = {"metric": "batched nll_chol bodies per second (one sgpr_fit_batch call per batch)", "value": B / t, "unit": "fits/s",
+           "n_gpus": 1, "steps": len(ts), "warmup": max(args.warmup, 1), "ms_per_step": t * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "%d independent fits of matrix order %d (N = %d points each), family %s" % (B, n, Np, args.family),
+                      "order_n": n, "batch": B},
+           "us_per_fit": t / B * 1e6, "tflops": B * flop_fit / t / 1e12,
+           "roofline": {"bound": "mfma", "kernel": "fit_batch_kernel (order <= 256) / mid_build + panel_batch + mid_syrk + mid_solve kernels",
+                        "achieved": B * flop_fit / t / 1e12, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": B * flop_fit / t / 1e12 / MFMA_F64_PEAK_TF, "traffic": None,
+                        "flop_per_fit": flop_fit, "timing": "host wall time of the whole call, median of %d" % len(ts)},
+           "all_info_zero": bool(np.all(np.asarray(info) == 0))}
+    if args.cpu_sample > 0:
+        import scipy.linalg
+        from oracle.oracle import Oracle, Ref
+        kind = "reference" if (Ref.available() and args.family in "AC") else "port"
+        bk = Ref().build_K if kind == "reference" else (lambda *a: Oracle().build_K(*a, threads=1))
+        m, t0, vals = 0, time.perf_counter(), []
+        while m < B and time.perf_counter() - t0 < 10.0:
+            K = bk(args.family, x[m], y[m], x[m], y[m], hyp[m])
+            K[np.diag_indices(n)] += s2[m]
+            Lf = scipy.linalg.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+            al = scipy.linalg.solve_triangular(Lf.T, scipy.linalg.solve_triangular(Lf, z[m], lower=True, check_finite=False),
+                                               lower=False, check_finite=False)
+            vals.append(0.5 * z[m] @ al + np.sum(np.log(Lf.diagonal())))
+            m += 1
+        tc = (time.perf_counter() - t0) / m
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": 1, "kind": kind,
+                               "sample": "%d of the %d problems, one after the other: the reference's build_K + scipy cholesky / "
+                                         "solve_triangular (BLAS threads as the box gives them)" % (m, B)}
+        out["nll_rel_err_vs_cpu"] = float(np.max(np.abs(np.asarray(nll[:m]) - np.asarray(vals)) / np.abs(vals)))
+    print(json.dumps(out))
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` typed by hand: start the N ranks as fresh child processes BEFORE
     anything in this process touches the GPU (a process that has initialised HIP must never be
@@ -172,6 +228,10 @@ def main():
     ap.add_argument("--nrhs", type=int, default=-1,
                     help="right-hand sides of the extra, separately timed block solve X = L^-T L^-1 B with the cached factor "
                          "(BASELINE config 05_tokamak: multi-RHS predict TRSM); default 64 with --d 3, else 0 = skip")
+    ap.add_argument("--batch", default="",
+                    help="ORDER,COUNT: instead of the big fit, time COUNT independent nll_chol bodies of matrix order ORDER in one "
+                         "batched call (sgpr_fit_batch: a CMA-ES generation / the Split_SympGPR sections) and print one JSON line "
+                         "with fits/s, TFLOP/s and the roofline fraction, the reference's CPU path beside it")
     ap.add_argument("--lower-only", action="store_true",
                     help="build only the lower triangle of K (what the factor reads) instead of the "
                          "full matrix build_K defines")
@@ -234,6 +294,9 @@ def main():
             sys.stderr.write("bench.py rank %d/%d FAILED in stage '%s': %s: %s\n" % (rank, world, dist_bench.STAGE[0], type(e).__name__, e))
             sys.stderr.flush()
             os._exit(3)
+
+    if args.batch:
+        return batch_leg(args)
 
     n_pts = args.n_pts
     d = args.d

@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define SGPR_ABI_VERSION 3   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
-                                3: sgpr_fit_solve_rhs_ms, sgpr_potrf_info_dev (entry points added, none changed) */
+                                3: sgpr_fit_solve_rhs_ms, sgpr_potrf_info_dev, sgpr_trim (entry points added, none changed) */
 
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
@@ -202,6 +202,12 @@ int sgpr_fit_batch_max_order(void);
 int sgpr_fit_batch(int family, int nbatch, int n_pts, const double *x, const double *y, const double *z,
                    const double *hyp, int nhyp, const double *sig2n, unsigned flags, double *alpha,
                    double *nll, int *info);
+
+/* Gives back what the CALLING thread's earlier calls keep for re-use: the device arena and page-locked staging block of
+ * sgpr_fit_batch (up to ~2 GiB after a large batch of order-2048 problems; they also shrink by themselves when a much smaller batch
+ * follows) and the pooled events of its factorisations.  Never needed for correctness; call it between a hyper-parameter search
+ * over small problems and a fit that wants the whole HBM.  No call of this thread may be in flight. */
+int sgpr_trim(void);
 
 /* ---- device-pointer primitives (the tiles a distributed driver composes) ------------------ */
 

@@ -66,6 +66,13 @@ int sgpr_probe_queue_postmortem(int always);
 /* TESTS ONLY: while on, every task-queue factorisation of this process gives up before it starts (the give-up word is raised and
  * the factor's info word set as by a hand-off that timed out) -- to exercise the callers' retry with the other driver */
 int sgpr_probe_queue_force_giveup(int on);
+/* Experiment knobs of the product library (they were SGPR_* environment variables up to round 3): set BEFORE the code that reads
+ * them runs for the first time in the process; each is read once.  Task-queue Cholesky: q_w (panel width, 512), q_tail (rows left
+ * to the look-ahead driver, 0), q_kcap, q_leaf_us / q_pair_us / q_fixed_us / q_band0_us (planner's cost model), q_pollcap (2),
+ * q_slack (CUs left empty, 0), q_nosync, q_debug.  Look-ahead driver: la_panel (3 = persistent panel kernel, 1 / 2 / 0 the
+ * multi-launch panels), la_t0 / la_t1 / la_t2 (width thresholds).  GEMM: gemm_small_tile, gemm_small_mb.  Batched fits:
+ * batch_two_min (512).  Block solves: trsm_chain (workgroups of the chain class, 0 = built-in). */
+int sgpr_probe_tune(const char *name, double value);
 /* the last sgpr_applymap_host of this process: K*-row evaluations (residuals of the implicit equation + q updates) summed over
  * its orbits, and the number of workgroups that share one orbit for ntest orbits on n0 training points */
 unsigned sgpr_probe_map_calls(void);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
     "sgpr_fit_solve_rhs_ms": (C.c_int, [_vp, _dp]),
     "sgpr_potrf_info_dev": (C.c_int, [C.c_int, _vp]),
+    "sgpr_trim": (C.c_int, []),
     "sgpr_fit_device_ptrs": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_vp)]),
     "sgpr_fit_destroy": (C.c_int, [_vp]),
     "sgpr_gram_pairs_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp,
@@ -130,6 +131,7 @@ PROBE_SIGNATURES = {
     "sgpr_probe_queue_trace_end": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]),
     "sgpr_probe_queue_postmortem": (C.c_int, [C.c_int]),
     "sgpr_probe_queue_force_giveup": (C.c_int, [C.c_int]),
+    "sgpr_probe_tune": (C.c_int, [C.c_char_p, C.c_double]),
     "sgpr_probe_map_calls": (C.c_uint, []),
     "sgpr_probe_map_team": (C.c_int, [C.c_int, C.c_int]),
     "sgpr_probe_queue_trace_clear": (C.c_int, []),

@@ -372,6 +372,9 @@ struct Arena {
         int cur = 0;
         SGPR_HIP(hipGetDevice(&cur));
         if (cur != device) { release(); device = cur; }
+        // grown for a large batch once, asked for a small one now: give the difference back (a CMA-ES population at order 2048
+        // must not keep gigabytes pinned under the full-size fit that follows it)
+        if (cap_dev > (256ull << 20) && need_dev * 4 < cap_dev) { if (dev) (void)hipFree(dev); dev = nullptr; cap_dev = 0; }
         if (need_dev > cap_dev) {
             if (dev) (void)hipFree(dev);
             dev = nullptr; cap_dev = 0;
@@ -394,6 +397,7 @@ inline size_t up256(size_t b) { return (b + 255) / 256 * 256; }
 }  // namespace
 
 int fit_batch_max_order() { return potrf_batch_max_order(); }
+int fit_batch_trim() { t_arena.release(); return 0; }     // the calling thread's device arena and pinned staging block
 
 namespace {
 
@@ -403,8 +407,8 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
 {
     const int npad = (n + (int)LEAF - 1) / (int)LEAF * (int)LEAF, W = npad / (int)LEAF;
     const size_t img = (size_t)npad * npad * 8, invb = (size_t)W * LEAF * LEAF * 8;
-    // at most ~6 GiB of images per chunk, at least one chip-full of strips (256 workgroups)
-    int chunk = (int)std::min<size_t>((size_t)nbatch, std::max<size_t>((256 + W - 1) / W, (6ull << 30) / img));
+    // at most ~2 GiB of images per chunk (64 problems of order 2048; round 3: 6 GiB), at least one chip-full of strips (256 workgroups)
+    int chunk = (int)std::min<size_t>((size_t)nbatch, std::max<size_t>((256 + W - 1) / W, (2ull << 30) / img));
     if (chunk > 16384) chunk = 16384;      // grid.z of the build launch
     const size_t C = (size_t)chunk;
     const size_t o_x = 0, o_y = o_x + up256(C * npts * 8), o_z = o_y + up256(C * npts * 8), o_kc = o_z + up256(C * n * 8),
@@ -448,7 +452,7 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
         }
         SGPR_CHECK_LAUNCH();
         int *fl = reinterpret_cast<int *>(dscr + o_fl);
-        static const int two_min = [] { const char *e = getenv("SGPR_BATCH_TWO_MIN"); return e ? atoi(e) : 512; }();
+        static const int two_min = (int)tune("batch_two_min", 512);
         if (npad <= two_min) {
             if ((rc = potrf_batch(nb, npad, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF, fl, dinfo, st)))
                 return rc;

@@ -4,6 +4,9 @@
 #include <new>
 #include <vector>
 
+#include <map>
+#include <mutex>
+#include <string>
 #include "common.h"
 
 namespace sgpr {
@@ -26,6 +29,23 @@ static int need_device()
         return SGPR_E_NODEVICE;
     }
     return 0;
+}
+
+// Experiment knobs of the kernels and drivers (panel widths, planner constants, tile-shape switches ...): NOT environment
+// variables of the product any more.  They keep their built-in values unless a measurement tool or a test sets them through
+// libsympgpr_probe.so (sgpr_probe_tune) before the code that reads them runs for the first time in the process.
+static std::mutex g_tune_mu;
+static std::map<std::string, double> g_tune;
+double tune(const char *name, double dflt)
+{
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    const auto it = g_tune.find(name);
+    return it == g_tune.end() ? dflt : it->second;
+}
+void tune_set(const char *name, double v)
+{
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    g_tune[name] = v;
 }
 
 // small RAII device buffer for the host-pointer calls
@@ -1059,6 +1079,12 @@ int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hy
     if (pdiff) SGPR_HIP(hipMemcpyAsync(pdiff, pd.p, out_bytes, hipMemcpyDeviceToHost, st));
     SGPR_HIP(hipStreamSynchronize(st));
     return applymap_status(tw.p, ntest, n0);
+}
+
+int sgpr_trim(void)
+{
+    (void)fit_batch_trim();
+    return potrf_trim();
 }
 
 int sgpr_profile_begin(void) { return gemm_profile_begin(); }

@@ -1049,6 +1049,19 @@ struct StreamJoin {
 hipStream_t g_side[64] = {};
 std::mutex g_side_mu;                                      // two fit handles may factor for the first time at once
 
+// The streams this library creates are handed back by an exit handler of the LIBRARY, registered when the first of them is
+// created: atexit handlers run in reverse order of registration, the HIP runtime registered its own when it was initialised
+// (before any stream could exist), so this one runs while the runtime is still whole.  Round 3 did this from the Python
+// binding only (a run under rocprofv3 --kernel-trace that had used the CU-masked streams crashed in an exit handler when
+// they were left to the runtime's own teardown); users of the C ABI get the same now.  No synchronisation here: a stream
+// that is still busy is released when its work ends.
+void release_all_streams_at_exit();
+void register_exit_release()
+{
+    static std::once_flag once;
+    std::call_once(once, [] { (void)atexit(release_all_streams_at_exit); });
+}
+
 int side_stream(hipStream_t caller, hipStream_t *out, int *dev_out)
 {
     hipStream_t *const side = g_side;
@@ -1066,6 +1079,7 @@ int side_stream(hipStream_t caller, hipStream_t *out, int *dev_out)
         if (cur != dev) SGPR_HIP(hipSetDevice(dev));
         hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&side[dev], hipStreamNonBlocking, hi);
+        if (e == hipSuccess) register_exit_release();
         if (cur != dev) (void)hipSetDevice(cur);
         SGPR_HIP(e);
     }
@@ -1142,6 +1156,7 @@ int queue_streams(QueueDevice &qd, int dev, int R, hipStream_t *sw, hipStream_t 
         for (int b = 0; b < 8 * R; ++b) { mp[b / 32] |= 1u << (b % 32); mw[b / 32] &= ~(1u << (b % 32)); }
         hipError_t e = hipExtStreamCreateWithCUMask(&qd.panels[R - 1], (uint32_t)words, mp.data());
         if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&qd.workers[R - 1], (uint32_t)words, mw.data());
+        if (e == hipSuccess) register_exit_release();
         if (cur != dev) (void)hipSetDevice(cur);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -1188,9 +1203,9 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     if (R > 4) return 1;
     hipStream_t sw = nullptr, sp = nullptr;
     if (queue_streams(qd, dev, R, &sw, &sp)) return 1;
-    // SGPR_Q_SLACK=<CUs of the worker set left empty> (default 0).  32 = one per shader engine: with that much room the
+    // tunable "q_slack" = <CUs of the worker set left empty> (default 0; sgpr_probe_tune).  32 = one per shader engine: with that much room the
     // workgroups of a preempted-and-restored grid all find a CU again (the stall) -- at 13 % of the throughput.
-    static const int qslack = [] { const char *e = getenv("SGPR_Q_SLACK"); return e ? atoi(e) : 0; }();
+    static const int qslack = (int)tune("q_slack", 0);
     const int nworkers = qd.ncu - 8 * R - std::max(0, std::min(qslack, 64));
     const cholq::Plan *plan = cholq::get_plan(n, nworkers);
     if (!plan) return 1;
@@ -1226,7 +1241,7 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     SGPR_HIP(hipEventRecord(qd.done, su));
     cholq::remember(ws, n, (int)(plan->tasks.size() / 2));
     cholq::remember_plan(plan);          // for the post-mortem probe
-    static const bool qdebug = getenv("SGPR_Q_DEBUG") != nullptr;
+    static const bool qdebug = tune("q_debug", 0) != 0;
     if (qdebug) {
         SGPR_HIP(hipStreamSynchronize(su));
         cholq::postmortem(false);
@@ -1240,11 +1255,41 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         // stream and on the high-priority side stream, all of them blocked by the joins above) the stall of DESIGN 3.9 was no
         // longer rare but came in the first factorisation, every time, ~4 ms in; with nothing enqueued behind them 400 in a
         // row were clean (and 1 in ~300 - 1700 still stalls, as with the whole factorisation in the queue).
-        static const bool nosync = getenv("SGPR_Q_NOSYNC") != nullptr;    // tests of the drain-and-relaunch recovery only
+        static const bool nosync = tune("q_nosync", 0) != 0;               // tests of the drain-and-relaunch recovery only
         if (!nosync) SGPR_HIP(hipStreamSynchronize(su));
         return potrf_lookahead(n - S, A + S + (size_t)S * lda, lda, ct, 0, off0 + S);
     }
     return 0;
+}
+
+void release_all_streams_at_exit()
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (int dev = 0; dev < ndev && dev < 64; ++dev) {
+        hipStream_t drop[9] = {};
+        int nd = 0;
+        {
+            std::lock_guard<std::mutex> lock(g_side_mu);
+            if (g_side[dev]) { drop[nd++] = g_side[dev]; g_side[dev] = nullptr; }
+        }
+        {
+            QueueDevice &qd = g_qdev[dev];
+            std::lock_guard<std::mutex> lock(qd.mu);
+            for (int r = 0; r < 4; ++r) {
+                if (qd.workers[r]) { drop[nd++] = qd.workers[r]; qd.workers[r] = nullptr; }
+                if (qd.panels[r]) { drop[nd++] = qd.panels[r]; qd.panels[r] = nullptr; }
+            }
+            qd.failed = true;                  // nothing new is started on this device from here on
+        }
+        if (!nd) continue;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        for (int q = 0; q < nd; ++q) (void)hipStreamDestroy(drop[q]);
+        if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+    }
+    (void)hipGetLastError();
 }
 
 int release_streams(int dev)
@@ -1310,10 +1355,7 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
         if (rc0) return rc0;
     }
     // Panel kernel usable?  (The multi-launch panels below remain for shapes it does not take and for A/B runs.)
-    static const int pmode = [] {
-        const char *e = getenv("SGPR_LA_PANEL");
-        return !e ? 3 : (e[0] == 'l' ? 1 : (e[0] == 'r' ? 2 : (e[0] == 'c' ? 0 : 3)));
-    }();
+    static const int pmode = (int)tune("la_panel", 3);     // 3: the persistent panel kernel; 1 left-looking, 2 recursive, 0 column-wise multi-launch panels
     const bool fused_cap = pmode == 3 && c.flags && n % LEAF == 0 && (lda & 1) == 0 && (((uintptr_t)A & 15) == 0) &&
                            off0 % LEAF == 0;
     // Block schedule.  nb > 0: uniform width (the caller's choice).  nb == 0: widths follow the order of
@@ -1324,10 +1366,10 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
     {
         // 2048-wide steps (k = 2048 updates: 61 TFLOP/s) pay off only when the early updates are long enough to
         // hide a 16-leaf chain: measured n = 32768 198.5 -> 194.0 ms, 49152 620 -> 603, but 16384 34.0 -> 35.6
-        static const int t0_env = [] { const char *e = getenv("SGPR_LA_T0"); return e ? atoi(e) : 0; }();
+        static const int t0_env = (int)tune("la_t0", 0);
         const int t0 = t0_env > 0 ? t0_env : (n >= 24576 ? 12288 : 1 << 30);
-        static const int t1 = [] { const char *e = getenv("SGPR_LA_T1"); return e ? atoi(e) : 6144; }();   // swept 2048 .. 9216: n = 12288 18.7 -> 18.1 ms, 16384 34.2 -> 33.4
-        static const int t2 = [] { const char *e = getenv("SGPR_LA_T2"); return e ? atoi(e) : 2048; }();
+        static const int t1 = (int)tune("la_t1", 6144);   // swept 2048 .. 9216: n = 12288 18.7 -> 18.1 ms, 16384 34.2 -> 33.4
+        static const int t2 = (int)tune("la_t2", 2048);
         for (int pos = 0; pos < n;) {
             starts.push_back(pos);
             const int rem = n - pos;
@@ -1511,6 +1553,19 @@ bool potrf_queue_mark_failed(hipStream_t st)
     const bool was_on = !qd.failed;
     qd.failed = true;
     return was_on;
+}
+
+// the calling thread's pooled events (every device); call with no factorisation of this thread in flight
+int potrf_trim()
+{
+    for (int dev = 0; dev < 64; ++dev) {
+        EventPool &p = t_event_pool[dev];
+        if (p.ev.empty() || p.top != 0) continue;
+        for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+        p.ev.clear();
+    }
+    (void)hipGetLastError();
+    return 0;
 }
 
 int release_device_streams(int dev)

@@ -47,12 +47,12 @@ struct Plan {
     unsigned *pinned = nullptr;            // page-locked copy for the upload: [starts | tasks]
 };
 
-// panel boundaries of the default schedule for order n (SGPR_Q_* override)
+// panel boundaries of the default schedule for order n (tunable "q_w": sgpr_probe_tune)
 std::vector<int> default_starts(int n);
 // host only: the ordered task list for given panel boundaries (all multiples of 256, starts[0] = 0, back() = n)
 // nq < 0: all panels
 int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out, int nq = -1);
-// the hand-over point of the schedule: with SGPR_Q_TAIL=<rows> (default 0: the queue runs everything) the queue runs the
+// the hand-over point of the schedule: with the tunable "q_tail" = <rows> (default 0: the queue runs everything; sgpr_probe_tune) the queue runs the
 // panels while more than that many rows are left and the look-ahead driver factors the rest.  Measured: no gain
 // (n = 16384: 30.6 - 31.6 ms against 30.0 for the whole factorisation in the queue and 32.2 for the look-ahead driver), and
 // the host has to wait between the two parts.

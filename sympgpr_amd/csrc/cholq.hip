@@ -75,7 +75,7 @@ std::vector<int> default_starts(int n)
     // Uniform panels (multiples of 256).  The planner below gives far tiles several panels per update task, so the panel
     // width no longer sets the k of the bulk of the flop; it sets the chain: a 512-wide panel costs the panel kernel
     // ~0.4 ms (4 leaf columns + the in-panel updates of its strips), and the next one can start one k = 512 tile later.
-    static const int w = std::min(2048, std::max(256, env_int("SGPR_Q_W", 512) / 256 * 256));
+    static const int w = std::min(2048, std::max(256, (int)tune("q_w", 512) / 256 * 256));
     std::vector<int> s;
     for (int pos = 0; pos < n; pos += w) s.push_back(pos);
     s.push_back(n);
@@ -126,7 +126,7 @@ struct Cand {
 
 int default_nq(int n, const std::vector<int> &starts)
 {
-    static const int tail = std::max(0, env_int("SGPR_Q_TAIL", 0));
+    static const int tail = std::max(0, (int)tune("q_tail", 0));
     const int nblk = (int)starts.size() - 1;
     int nq = nblk;
     while (nq > 1 && n - starts[nq - 1] <= tail) --nq;      // panel nq - 1 still has more than `tail` rows under and beside it
@@ -150,11 +150,11 @@ int build_plan(int n, const std::vector<int> &starts, int nworkers, Plan &out, i
     const int S = starts[nq];          // the queue's part: columns [0, S)
     Model M;
     // (12 up to n = 18432: 1 - 3 % faster there than 16 -- n = 14336 21.6 vs 22.2 ms, 16384 29.1 vs 29.5 -- the same above)
-    M.kcap = std::max(1, std::min(16, env_int("SGPR_Q_KCAP", n <= 18432 ? 12 : 16)));
-    M.leaf = env_int("SGPR_Q_LEAF_US", (int)M.leaf);
-    M.pair = env_int("SGPR_Q_PAIR_US", (int)M.pair);
-    M.fixed = env_int("SGPR_Q_FIXED_US", (int)M.fixed);
-    M.band0 = env_int("SGPR_Q_BAND0_US", (int)M.band0);
+    M.kcap = std::max(1, std::min(16, (int)tune("q_kcap", n <= 18432 ? 12 : 16)));
+    M.leaf = tune("q_leaf_us", M.leaf);
+    M.pair = tune("q_pair_us", M.pair);
+    M.fixed = tune("q_fixed_us", M.fixed);
+    M.band0 = tune("q_band0_us", M.band0);
     out = Plan();
     out.n = n; out.nblk = nblk; out.starts = starts; out.nworkers = nworkers; out.nq = nq;
     for (int k = 0; k < nblk; ++k) out.wmax = std::max(out.wmax, starts[k + 1] - starts[k]);
@@ -718,7 +718,7 @@ int launch_workers(const Plan &p, const Ws &w, double *A, size_t lda, const doub
     a.flags = flags; a.pstride = pflag_stride; a.inv = inv; a.dinfo = dinfo;
     a.trace = (g_trace && p.tasks.size() / 2 <= g_trace_cap) ? g_trace : nullptr;
     a.census = a.trace ? g_trace + TRACE_STRIDE * g_trace_cap : nullptr;
-    static const int pollcap = std::max(1, std::min(8, env_int("SGPR_Q_POLLCAP", 2)));
+    static const int pollcap = std::max(1, std::min(8, (int)tune("q_pollcap", 2)));
     a.pollcap = (unsigned)pollcap;
     const int grid = std::max(1, std::min(p.nworkers, (int)(p.tasks.size() / 2)));
     // Q_INSTANCES worker kernels back to back, a rewind of the ticket head between them: the first normally runs the whole

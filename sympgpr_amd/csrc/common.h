@@ -10,6 +10,9 @@
 namespace sgpr {
 
 void set_error(const std::string &msg);
+// experiment knobs (capi.hip): built-in value unless set through libsympgpr_probe.so before first use
+double tune(const char *name, double dflt);
+void tune_set(const char *name, double v);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 #define SGPR_HIP(call)                                                          \
@@ -144,6 +147,8 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
 
 // ---- batch.hip : many small fits (order <= 256 each) in one launch, one workgroup per problem
 int fit_batch_max_order();
+int fit_batch_trim();                            // release the calling thread's batch arena (device + pinned host)
+int potrf_trim();                                // ... and its pooled events
 int fit_batch(int family, int nbatch, int npts, const double *x, const double *y, const double *z, const double *hyp,
               int nhyp, const double *sig2n, unsigned flags, double *alpha, double *nll, int *info);
 

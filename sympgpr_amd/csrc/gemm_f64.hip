@@ -200,14 +200,14 @@ static int gemm_launch(int m, int n, int k, double alpha, const double *A, size_
     // inside the n = 131072 factorisation the 256x128 shape wins (61.7 vs 58.4 TFLOP/s overall:
     // a third less operand traffic per flop, and the triangular tile map below needs its 2:1
     // aspect).  So: 256x128 whenever it yields >= 256 workgroups, 128x128 below.
-    // SGPR_GEMM_TILE=small forces the 128x128 shape (A/B experiments).
-    static const bool prefer_big = [] { const char *e = getenv("SGPR_GEMM_TILE"); return !(e && e[0] == 's'); }();
-    // SGPR_GEMM_SMALL_MB=<MB>: take the 128x128 shape for products whose operand panels are smaller than
+    // tunable "gemm_small_tile" = 1 forces the 128x128 shape (A/B experiments, sgpr_probe_tune).
+    static const bool prefer_big = tune("gemm_small_tile", 0) == 0;
+    // tunable "gemm_small_mb" = <MB>: take the 128x128 shape for products whose operand panels are smaller than
     // that (experiments; default off).  Alone, lower-triangular m = 15360, 256x128 vs 128x128 tiles:
     // k = 256 47.4 vs 55.8, 512 49.0 vs 52.1, 1024 56.8 vs 61.2, 2048 61.2 vs 64.3 TFLOP/s -- but inside the
     // blocked factorisation, beside the panel stream, the small shape LOSES (n = 16384 39.0 vs 34.5 ms,
     // n = 32768 231 vs 208 ms): two of its workgroups share a CU and its LDS bandwidth with nothing to spare.
-    static const double small_mb = [] { const char *e = getenv("SGPR_GEMM_SMALL_MB"); return e ? atof(e) : 0.0; }();
+    static const double small_mb = tune("gemm_small_mb", 0.0);
     const double op_bytes = 8.0 * (double)k * ((A == B && lda == ldb) ? (double)std::max(m, n) : (double)m + n);
     const bool small_k = op_bytes <= small_mb * 1e6 && m > 128 && n > 128;
     if (n <= 128 && m <= 32768 && !(dbg & 8)) {

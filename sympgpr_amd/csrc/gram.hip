@@ -309,7 +309,7 @@ __global__ __launch_bounds__(GT) void predict_reg_kernel(int n0, const double *q
 struct MapArgs {
     int nm, ntest, n0, n0p, mode, maxiter;
     int S;                                // workgroups per orbit (the team): each sums its share of the training points
-    unsigned long long *tw;               // team exchange words: [orbit][member][wave][parity][2] 16-byte granules {value, sequence}, zero on entry
+    unsigned long long *tw;               // team exchange words: [orbit][member][parity][2] 16-byte granules {value, sequence}, zero on entry
     int *err;                             // set when a team member gave up waiting for another
     double tol;
     const double *xtr, *ytr, *alpha;      // symplectic GP: n0 points, alpha 2 n0
@@ -319,6 +319,7 @@ struct MapArgs {
     KConst kc, kcp;
 };
 
+template <int TT>
 __device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
 {
     for (int o = 32; o > 0; o >>= 1) {
@@ -331,8 +332,10 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
         sh[2 * (threadIdx.x >> 6) + 1] = b;
     }
     __syncthreads();
-    a = sh[0] + sh[2] + sh[4] + sh[6];
-    b = sh[1] + sh[3] + sh[5] + sh[7];
+    double x = 0.0, y = 0.0;
+#pragma unroll
+    for (int w = 0; w < TT / 64; ++w) { x += sh[2 * w]; y += sh[2 * w + 1]; }
+    a = x; b = y;
 }
 
 // 16-byte {value, sequence number} granules, written by one write-through store and read by one load that passes the vector L1
@@ -356,31 +359,29 @@ __device__ __forceinline__ void granule_load2(const unsigned long long *p, uint4
 // of its orbit.  For large training sets (the drivers use 20 - 80 points; BASELINE config 05 has 16384) S workgroups share an
 // orbit: every residual is summed in S parts, exchanged through a.tw and added up in member order by every member alike -- all
 // members then hold the same bits, take the same branches and need no leader.  Ntest = 37 orbits no longer mean 37 CUs.
-template <int FAM>
-__global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
+// TT threads: 256 for one workgroup per orbit (the drivers' sizes: latency of a few dozen points), MAP_TEAM_T for the teams
+template <int FAM, int TT>
+__global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
 {
-    __shared__ double sh[8];
-    __shared__ double sp[2][8 * (GT / 64)];
+    __shared__ double sh[2 * (TT / 64)];
+    __shared__ double sp[2][8];
     const int S = a.S, k = blockIdx.x / S, me = blockIdx.x - k * S;
     unsigned seq = 0;
     bool lost = false;                                  // a team member did not answer in time: the orbit is lost (NaN), a.err says why
-    // (x, y) := sum over the team of every thread's (x, y), identical bits in every member.  Every WAVE publishes its own part
-    // (no block-wide reduction in front of the exchange), lanes 0 .. 4 S - 1 of wave 0 collect them.
+    // (x, y) := sum over the team of every thread's (x, y), identical bits in every member: the workgroup's own sum first, then
+    // ONE pair of granules per member, collected by lanes 0 .. S - 1.  (Tried: every wave publishing its own part, 4 S and 16 S
+    // granule pairs to collect -- no gain at 256 threads, 40 instead of 65 G pair evaluations per second at 1024.)
     auto team_sum2 = [&](double &x, double &y) {
-        if (S == 1) { block_sum2(x, y, sh); return; }
-        for (int o = 32; o > 0; o >>= 1) {
-            x += __shfl_down(x, o, 64);
-            y += __shfl_down(y, o, 64);
-        }
+        block_sum2<TT>(x, y, sh);
+        if (S == 1) return;
         ++seq;
-        constexpr int NW = GT / 64;
-        if ((threadIdx.x & 63) == 0) {
-            unsigned long long *mine = a.tw + ((((size_t)k * S + me) * NW + (threadIdx.x >> 6)) * 2 + (seq & 1u)) * 4;
+        if (threadIdx.x == 0) {
+            unsigned long long *mine = a.tw + (((size_t)k * S + me) * 2 + (seq & 1u)) * 4;
             granule_store(mine, x, seq);
             granule_store(mine + 2, y, seq);
         }
-        if (threadIdx.x < (unsigned)(S * NW)) {
-            const unsigned long long *theirs = a.tw + (((size_t)k * S * NW + threadIdx.x) * 2 + (seq & 1u)) * 4;
+        if (threadIdx.x < (unsigned)S) {
+            const unsigned long long *theirs = a.tw + (((size_t)k * S + threadIdx.x) * 2 + (seq & 1u)) * 4;
             uint4_t u, v;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             unsigned it = 0;
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
         }
         __syncthreads();
         double sx = 0.0, sy = 0.0;
-        for (int m = 0; m < S * NW; ++m) { sx += sp[0][m]; sy += sp[1][m]; }
+        for (int m = 0; m < S; ++m) { sx += sp[0][m]; sy += sp[1][m]; }
         x = sx; y = sy;
         __syncthreads();
     };
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
     auto rows = [&](double q, double P, double &r1, double &r2) {   // Kstar(1,:).alpha, Kstar(2,:).alpha
         r1 = 0.0; r2 = 0.0;
         ++ncalls;
-        for (int j = me * GT + threadIdx.x; j < a.n0; j += S * GT) {
+        for (int j = me * TT + threadIdx.x; j < a.n0; j += S * TT) {
             double kxx, kxy, kyy;
             pair_eval<FAM, false>(a.xtr[j], a.ytr[j], q, P, a.kc, kxx, kxy, kyy);
             const double a1 = a.alpha[j], a2 = a.alpha[a.n0 + j];
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(GT) void applymap_kernel(const MapArgs a)
     };
     auto guess = [&](double q, double p) {
         double r = 0.0, z = 0.0;
-        for (int j = me * GT + threadIdx.x; j < a.n0p; j += S * GT)
+        for (int j = me * TT + threadIdx.x; j < a.n0p; j += S * TT)
             r += a.kcp.sig * kern_eval<FAM, false>(a.xtrp[j], a.ytrp[j], q, p, a.kcp) * a.alphap[j];
         team_sum2(r, z);
         return r;
@@ -637,7 +638,8 @@ int predict_rows(int family, int m, const double *q, const double *P, int n0, co
 }
 
 // Workgroups per orbit: as many as fill the chip (256 CUs) with ntest orbits, at most 8, and no more than the training set can
-// feed with two rounds of 256 points each -- the drivers' own sizes (20 - 80 points) keep one workgroup per orbit.
+// feed with a round of 512 points each -- the drivers' own sizes (20 - 80 points) keep one workgroup per orbit.
+constexpr int MAP_TEAM_T = 512;     // threads of a team member
 int applymap_team(int ntest, int n0)
 {
     int S = ntest > 0 ? 256 / ntest : 1;
@@ -646,7 +648,7 @@ int applymap_team(int ntest, int n0)
 }
 size_t applymap_team_ws(int ntest, int n0)
 {
-    return ((size_t)ntest * applymap_team(ntest, n0) * (GT / 64) * 2 * 4 + 2) * sizeof(unsigned long long);    // granules + the error word
+    return ((size_t)ntest * applymap_team(ntest, n0) * 2 * 4 + 2) * sizeof(unsigned long long);    // granules + the error word
 }
 
 // team_ws: applymap_team_ws(ntest, n0) bytes of device scratch (cleared here)
@@ -659,11 +661,12 @@ int applymap(int family, int mode, int nm, int ntest, int n0, const double *xtr,
     const int S = applymap_team(ntest, n0);
     SGPR_HIP(hipMemsetAsync(team_ws, 0, applymap_team_ws(ntest, n0), st));
     unsigned long long *tw = static_cast<unsigned long long *>(team_ws);
-    int *err = reinterpret_cast<int *>(tw + (size_t)ntest * S * (GT / 64) * 2 * 4);
+    int *err = reinterpret_cast<int *>(tw + (size_t)ntest * S * 2 * 4);
     MapArgs a{nm, ntest, n0, n0p, mode, 60, S, tw, err, 1e-13, xtr, ytr, alpha, xtrp, ytrp, alphap, Q0, P0, qmap, pmap, pdiff, kc, kcp};
     return dispatch_family(family, [&](auto fam) {
         constexpr int F = decltype(fam)::value;
-        hipLaunchKernelGGL((applymap_kernel<F>), dim3(ntest * S), dim3(GT), 0, st, a);
+        if (S == 1) hipLaunchKernelGGL((applymap_kernel<F, GT>), dim3(ntest), dim3(GT), 0, st, a);
+        else        hipLaunchKernelGGL((applymap_kernel<F, MAP_TEAM_T>), dim3(ntest * S), dim3(MAP_TEAM_T), 0, st, a);
         SGPR_CHECK_LAUNCH();
         return 0;
     });
@@ -676,7 +679,7 @@ int applymap_status(const void *team_ws, int ntest, int n0)
 {
     const unsigned long long *tw = static_cast<const unsigned long long *>(team_ws);
     int hh[2] = {0, 0};
-    SGPR_HIP(hipMemcpy(hh, tw + (size_t)ntest * applymap_team(ntest, n0) * (GT / 64) * 2 * 4, sizeof(hh), hipMemcpyDeviceToHost));
+    SGPR_HIP(hipMemcpy(hh, tw + (size_t)ntest * applymap_team(ntest, n0) * 2 * 4, sizeof(hh), hipMemcpyDeviceToHost));
     g_last_map_calls.store((unsigned)hh[1]);
     const int h = hh[0];
     if (h) { set_error("applymap: a workgroup of an orbit's team did not answer in time"); return SGPR_E_HIP; }

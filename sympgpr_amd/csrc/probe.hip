@@ -403,6 +403,12 @@ extern "C" int sgpr_probe_queue_trace_end(unsigned long long *out, int max_tasks
 
 extern "C" int sgpr_probe_queue_postmortem(int always) { return cholq::postmortem(always != 0); }
 extern "C" int sgpr_probe_queue_force_giveup(int on) { cholq::force_giveup(on); return 0; }
+extern "C" int sgpr_probe_tune(const char *name, double value)
+{
+    if (!name) { set_error("probe_tune: null name"); return SGPR_E_ARG; }
+    tune_set(name, value);
+    return 0;
+}
 extern "C" unsigned sgpr_probe_map_calls(void) { return applymap_last_calls(); }
 extern "C" int sgpr_probe_map_team(int ntest, int n0) { return applymap_team(ntest, n0); }
 

@@ -718,7 +718,7 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
     if (!trsm_strips_ok(n, L, ldl)) { set_error("potrs_strips: shape not supported"); return SGPR_E_ARG; }
     const int T = n / LEAF;
     // chain class: four quarters of the strips next to the frontier, each MS_F + 1 products long
-    static const int nchain_env = [] { const char *e = getenv("SGPR_TRSM_CHAIN"); return e ? atoi(e) : 0; }();
+    static const int nchain_env = (int)tune("trsm_chain", 0);
     int nchain = nchain_env > 0 ? nchain_env : 4 * (MS_F + 2);
     if (nchain > 4 * T) nchain = 4 * T;
     const int nstream = T < 256 - nchain ? T : 256 - nchain;

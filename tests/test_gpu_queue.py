@@ -11,10 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_check(sizes, extra_env=None):
+def run_check(sizes, tune=()):
     env = dict(os.environ, SGPR_POTRF_Q="1", SGPR_Q_MIN="2048")
-    env.update(extra_env or {})
-    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "queue_check.py")] + [str(s) for s in sizes],
+    return subprocess.run([sys.executable, os.path.join(ROOT, "tools", "queue_check.py")] + [str(s) for s in sizes] + list(tune),
                           env=env, capture_output=True, text=True, timeout=600)
 
 
@@ -27,11 +26,11 @@ def test_queue_factor_vs_scipy():
 
 def test_queue_recovers_when_workgroups_are_switched_out():
     """The reproducer of DESIGN 3.9: the queue factors the first panels, the look-ahead driver's launches for the rest are
-    enqueued BEHIND the persistent kernels (SGPR_Q_TAIL + SGPR_Q_NOSYNC) -- on this platform that switches the running
+    enqueued BEHIND the persistent kernels (the tunables q_tail + q_nosync, set through libsympgpr_probe.so) -- on this platform that switches the running
     queues out and in, and some workgroups of the exactly-full worker grid do not get a CU back.  Before the drain-and-
     relaunch recovery this stalled in the first factorisation, every time; now the waiters notice that nothing moves,
     leave, the stranded workgroups finish, and the next kernel instance carries on.  Also the hand-over variant itself."""
-    r = run_check([14336], {"SGPR_Q_TAIL": "6144", "SGPR_Q_NOSYNC": "1"})
+    r = run_check([14336], ["q_tail=6144", "q_nosync=1"])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count(" ok") == 1, r.stdout
 

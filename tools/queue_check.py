@@ -3,7 +3,13 @@ import sys, os, time
 import numpy as np
 import scipy.linalg
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sympgpr_amd import ops
+from sympgpr_amd import ops, _lib as L
+
+# name=value arguments set experiment knobs of the library through libsympgpr_probe.so before anything runs (q_tail=6144 ...)
+for kv in [a for a in sys.argv[1:] if "=" in a]:
+    k, v = kv.split("=")
+    L.check(L.load_probe_library().sgpr_probe_tune(k.encode(), float(v)))
+sys.argv = [a for a in sys.argv if "=" not in a]
 
 rng = np.random.default_rng(7)
 for n in [int(a) for a in sys.argv[1:]]:
