@@ -417,16 +417,25 @@ def main():
                            "sum_launch_ms_alone": alone_ms, "sum_launch_ms_overlapped": ov_ms,
                            "launches_untimed": int(prof[11]),
                            "largest_launch_tflops": prof[6] / (prof[7] * 1e-3) / 1e12 if prof[7] > 0 else None}
-    else:
-        # no launch of the grid-wide MFMA kernel in this factorisation: orders 13312 .. 28672 run every trailing update inside
-        # ONE persistent worker kernel (the task-queue Cholesky), whose duration is the factor stage itself
+    elif 13312 <= n <= 28672 and n % 256 == 0 and os.environ.get("SGPR_POTRF_Q", "1") != "0":
+        # no launch of the grid-wide MFMA kernel in this factorisation: orders 13312 .. 28672 run every trailing update inside the
+        # persistent worker kernel of the task-queue Cholesky (several instances are enqueued, all but the first
+        # normally find nothing to do).  Its duration is the factor stage; the flop are the whole factorisation's (the panel
+        # kernel's share, the 128 x 128 leaves and their rows, is < 2 % at these orders and is counted in).
         ach = out["chol_tflops"]
-        out["roofline"] = {"bound": "mfma", "kernel": "chol_queue_kernel (persistent worker grid: every trailing update and rows-below "
-                                                      "solve of the factorisation in one launch, same 256x128 fp64 MFMA body)",
+        out["roofline"] = {"bound": "mfma", "kernel": "chol_queue_kernel + panel_seq_kernel (task-queue Cholesky: every trailing update and "
+                                                      "rows-below solve in one persistent worker grid, same 256x128 fp64 MFMA body)",
                            "achieved": ach, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F64_PEAK_TF,
                            "traffic": None, "traffic_source": None,
-                           "timing": "HIP events around the factor stage of the timed steps (the kernel spans the stage)",
-                           "launches": 1, "flop_per_launch": n**3 / 3.0, "avg_launch_ms": out["chol_ms"]}
+                           "timing": "HIP events around the factor stage of the timed steps (the persistent kernels span the stage)",
+                           "launches": None, "flop_per_launch": None, "flop": n**3 / 3.0, "stage_ms": out["chol_ms"]}
+    else:
+        # small orders / SGPR_POTRF_Q=0 runs without a single timed launch of the 256x128 kernel: the stage figure, labelled as such
+        ach = out["chol_tflops"]
+        out["roofline"] = {"bound": "mfma", "kernel": "factor stage as a whole (no launch of gemm_nt_kernel<256,128> was timed at this order)",
+                           "achieved": ach, "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_F64_PEAK_TF,
+                           "traffic": None, "traffic_source": None, "timing": "HIP events around the factor stage of the timed steps",
+                           "launches": None, "flop_per_launch": None, "flop": n**3 / 3.0, "stage_ms": out["chol_ms"]}
     out["roofline_gram"] = {"bound": "hbm", "kernel": "gram_pairs_kernel" if d == 1 else "gram_nd_kernel", "achieved": out["gram_gb_s"],
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["gram_gb_s"] / HBM_PEAK_GBS,
                             "traffic": traffic.get("gram"), "traffic_source": traffic_source,
