@@ -98,6 +98,7 @@ struct TrsmArgs {
     int *state;            // [0] stream ticket, [1] chain ticket, [2] give-up flag
     int *ready;            // [c] strips whose quarter c is published (ticket order)
     unsigned long long *dbg;   // debug builds: 16 time stamps (100 MHz) per strip, or null
+    int fake_b;                // debug builds, experiment: the streamed products read one cache-hot segment chunk over and over
 };
 
 #ifdef SGPR_TRSM_DBG
@@ -466,7 +467,8 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, int tk, Ctl &c, d
     zero_acc(acc);
     if (ns > 0) {
         const OpStream oa{tile_ptr(0), (unsigned)a.ldl, fwd ? (long)MS_BK * (long)a.ldl : (long)MS_BK, fwd ? 0L : -2L * LEAF};
-        const OpStream ob{seg_ptr(0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
+        OpStream ob{seg_ptr(0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
+        if (TRSM_DBG && a.fake_b) { ob.p0 = a.P + (size_t)(fwd ? 0 : T - 1) * LEAF * MS_YLD; ob.step = 0; ob.adj = 0; }   // experiment: every segment chunk from ONE cache-hot place (wrong results)
         if (!stream_products<AT, false, true>(acc, ns, oa, ob, c, smem)) return false;
     }
     stamp(2);
@@ -730,7 +732,7 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
         SGPR_CHECK_LAUNCH();
         SGPR_HIP(hipMemsetAsync(state, 0, TRSM_STATE_INTS * sizeof(int), st));
         SGPR_HIP(hipMemsetAsync(I1, 0xFF, 2 * img * sizeof(double), st));       // P and S of the forward solve
-        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, state, state + 8, nullptr};
+        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
         const bool dbg = TRSM_DBG && getenv("SGPR_TRSM_DBG") != nullptr;
         if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * 16 * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * 16 * T); }
         hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);

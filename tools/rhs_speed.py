@@ -11,7 +11,13 @@ ap.add_argument("--d", type=int, default=1)
 ap.add_argument("--nrhs", type=int, default=64)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("npts", type=int, nargs="+")
+ap.add_argument("--tune", action="append", default=[], help="name=value experiment knobs (libsympgpr_probe.so), before anything runs")
 a = ap.parse_args()
+if a.tune:   # TUNE
+    from sympgpr_amd import _lib as L
+    for kv in a.tune:
+        k, v = kv.split("=")
+        L.check(L.load_probe_library().sgpr_probe_tune(k.encode(), float(v)))
 for N in a.npts:
     if a.d == 1:
         q, P, z, hyp, s2 = synth(N)
