@@ -7,8 +7,8 @@
 // Round 3 solved this by recursion over the MFMA GEMM kernel: ~3000 dependent launches at n = 98304, most of them one
 // 64 x 128 tile (n = 16384, 64 right-hand sides: 44.8 ms).  Here one launch per triangular solve, two classes of workgroups:
 //
-//   STREAM class (most of the chip): strip s (128 rows forward / 128 columns backward) is one task, dealt in dependency
-//   order by a ticket.  It streams the tiles of L of its strip ONCE for all 64 right-hand sides (LDS-DMA into a 3-deep ring
+//   STREAM class (most of the chip): strip s (128 rows forward / 128 columns backward) is one task (long strips: several, see
+//   piece_of), dealt in dependency order by a ticket.  It streams the tiles of L of its strip ONCE for all 64 right-hand sides (LDS-DMA into a 3-deep ring
 //   for L and a 2-deep ring for the solved segments, 128 x 32 x 64 products per chunk on the matrix cores) up to F tiles short
 //   of the diagonal, and hands S = B_s - sum_{q < tk-F} op(L_q) Y_q to the chain.  Before that it folds the F tiles next to the
 //   diagonal into the leaf inverse, M_f = op(inv_s) op(L(s, s-+f)) (128^3 products, off the chain).
@@ -62,12 +62,13 @@ static_assert((MS_BK == 16 || MS_BK == 32) && CPT == 1 << CPT_SH, "chunks per ti
 constexpr int MS_YLD = TRSM_YLD;             // 80: row stride of the images (global AND LDS)
 constexpr int MS_F = TRSM_FOLD;              // tiles next to the diagonal that are folded into the leaf inverse
 constexpr int XT_LD = MS_BK + 2;             // "T" image of a chunk whose reduction index is contiguous in memory: [row][MS_BK + 2]
-constexpr int NPAD = 8;                      // row pad of the "N" images: [k][ROWS + 8] (2-way bank conflicts on half the lanes of a
-                                             // fragment read -- LDS is a quarter busy here -- but more stages fit)
-// ring slots, in doubles: the images ("T" [128][MS_BK + 2] / "N" [MS_BK][136] for L, "N" [MS_BK][72] / "T" [64][MS_BK + 2] for the
+constexpr int NPAD = 16;                     // row pad of the "N" images: [k][ROWS + 16], rows 32 banks apart -- the four k-rows of a
+                                             // fragment read fall on disjoint banks per half wave.  (A pad of 8 -- two-way conflicts on
+                                             // half the lanes -- measured the same: LDS is a quarter busy here.)
+// ring slots, in doubles: the images ("T" [128][MS_BK + 2] / "N" [MS_BK][144] for L, "N" [MS_BK][80] / "T" [64][MS_BK + 2] for the
 // segments) rounded up to whole wave instructions per issuing wave
 constexpr int A_ELEMS = MS_BK == 16 ? 2304 : 4608;
-constexpr int B_ELEMS = MS_BK == 16 ? 1280 : 2304;
+constexpr int B_ELEMS = MS_BK == 16 ? 1280 : 2560;
 // What bounds the products of a stream task on a quiet chip turned out to be INSTRUCTION ISSUE, not memory: one wave issues at
 // most one instruction per ~4 cycles, and the first forms of this loop spent 340 of them per 16 MFMAs, most on index arithmetic
 // (10-12 us per tile whatever the ring depth, the pad or the barrier form).  Hence running pointers (Copier), role-specialised
@@ -95,6 +96,8 @@ struct TrsmArgs {
     double *P;             // image of the solution, all-ones on entry
     double *S;             // image of the hand-over stream -> chain, all-ones on entry
     double *M;             // T * MS_F * MFRAG doubles: the folded tiles, fragment order
+    double *X;             // partial sums of the strips that are streamed in several pieces, XPART doubles each, all-ones on entry
+    int piece;             // most tiles one stream task takes (piece_of)
     int *state;            // [0] stream ticket, [1] chain ticket, [2] give-up flag
     int *ready;            // [c] strips whose quarter c is published (ticket order)
     unsigned long long *dbg;   // debug builds: 16 time stamps (100 MHz) per strip, or null
@@ -108,6 +111,33 @@ constexpr bool TRSM_DBG = false;   // per-strip time stamps (experiments: make E
 #endif
 
 constexpr unsigned long long UNPUBLISHED = ~0ull;
+
+// A stream ticket = one PIECE of a strip.  Strip tk streams ns = tk - MS_F tiles; dealt whole, the last tickets are the longest
+// tasks of the launch (n = 98304: 7.7 ms each of 17) and the chip idles behind them for half of that on average.  So a strip
+// with more than C tiles goes out as np = ceil(ns / C) tickets over equal shares of its tiles, oldest segments first: the
+// first np - 1 (helpers) leave their 128 x 64 partial sums in X, the last one (the owner: the youngest segments, the fold and
+// the hand-over S) adds them in piece order.  Tickets stay in dependency order: a helper waits only for segments older than
+// the owner's, the owner for its helpers (smaller tickets).
+struct Piece { int tk, p, np, x0; };         // strip, piece, pieces, slot of the strip's first partial sum in X
+constexpr size_t XPART = (size_t)LEAF * 64;
+__host__ __device__ inline Piece piece_of(int u, int C)
+{
+    const int g0 = TRSM_FOLD + C + 1;        // strips 0 .. F + C: one piece
+    if (u < g0) return Piece{u, 0, 1, 0};
+    // group m >= 1: the C strips with m C < ns <= (m + 1) C, m + 1 tickets each
+    u -= g0;
+    int m = 1, x = 0;
+    while (u >= C * (m + 1)) { u -= C * (m + 1); x += C * m; ++m; }
+    const int j = u / (m + 1);
+    return Piece{g0 + (m - 1) * C + j, u % (m + 1), m + 1, x + j * m};
+}
+// partial sums of a solve with T strips (host: sizes the scratch)
+inline size_t piece_partials(int T, int C)
+{
+    size_t x = 0;
+    for (int tk = TRSM_FOLD + C + 1; tk < T; ++tk) x += (size_t)((tk - TRSM_FOLD + C - 1) / C - 1);
+    return x;
+}
 constexpr unsigned long long WAIT_LIMIT_TICKS = 500000000ull;   // 5 s of the 100 MHz real-time counter
 
 __device__ __forceinline__ void store_sc1(double *p, double v)
@@ -133,7 +163,7 @@ __device__ __forceinline__ void dma16(const double *src, double *lds_dst)
 }
 
 // ---- LDS-DMA staging.  One operand of a (ROWS x 32) chunk product; `p` points at element (row 0, reduction index 0):
-//   N: the non-reduction index is contiguous in memory (element (row, k) at row + k ld)  -> image [k][ROWS + 8]
+//   N: the non-reduction index is contiguous in memory (element (row, k) at row + k ld)  -> image [k][ROWS + 16]
 //   T: the reduction index is contiguous in memory     (element (row, k) at k + row ld)  -> image [row][34]
 // A wave instruction moves 64 granules of 16 B to 1 KiB of consecutive LDS; which granule a lane fetches is free, so the
 // padded images are filled in image order (pad granules re-fetch a neighbour).  The per-lane offsets depend on the
@@ -273,6 +303,7 @@ struct Ctl {
     int *state, *ready;
     int *sh;               // 2 ints of LDS
     int known;             // strips known to be published in all four quarters (ticket order)
+    int qbase;             // the polled streams: dependency index of the first tile of the piece
     int tid;
     unsigned long long *dbg_wait;   // debug builds: [0] time of the first wait that had to poll, [1] the tile it was for
 };
@@ -293,7 +324,7 @@ __device__ __forceinline__ bool wait_ready(Ctl &c, int need)
     if (c.tid == 0) {
         int v;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        if (TRSM_DBG && c.dbg_wait && c.dbg_wait[0] == 0) { c.dbg_wait[0] = t0; c.dbg_wait[1] = (unsigned long long)need; }
+        if (TRSM_DBG && c.dbg_wait && c.dbg_wait[0] == 0) { c.dbg_wait[0] = t0; c.dbg_wait[1] = (unsigned long long)(need - c.qbase); }
         unsigned it = 0;
         bool ok = true;
         for (;;) {
@@ -345,7 +376,7 @@ __device__ __forceinline__ bool stream_loop(double4_t (&acc)[2][2], int ntiles, 
     static_assert(MS_BK == 16 ? (CA::NX * (A_STAGES - 2) == 15 && CB::NX * (B_STAGES - 2) == 5)
                               : (CA::NX * (A_STAGES - 2) == 6 && CB::NX * (B_STAGES - 2) == 0), "the steady-state vmcnt immediates below");
     int ia = 0, ib = 0;                                      // next chunk of A / of B to be asked for
-    int blimit = POLL ? min(nch, CPT * c.known) : nch;       // chunks of B that may be asked for
+    int blimit = POLL ? min(nch, CPT * (c.known - c.qbase)) : nch;   // chunks of B that may be asked for
     for (; ia < nch && ia < A_STAGES - 1; ++ia)
         if (ROLE == 0) ca.issue();
     int sa_slot = 0, sb_slot = 0;                            // ring slots of chunk t
@@ -353,8 +384,8 @@ __device__ __forceinline__ bool stream_loop(double4_t (&acc)[2][2], int ntiles, 
     for (int t = 0; t < nch; ++t) {
         if (ib <= t) {
             // chunk t's segment has not even been asked for (start, or the frontier): wait until it may be
-            if (POLL && !wait_ready(c, (t >> CPT_SH) + 1)) return false;
-            if (POLL) blimit = min(nch, CPT * c.known);
+            if (POLL && !wait_ready(c, c.qbase + (t >> CPT_SH) + 1)) return false;
+            if (POLL) blimit = min(nch, CPT * (c.known - c.qbase));
             if (ROLE == 1) cb.issue();
             ib = t + 1;
         }
@@ -417,8 +448,10 @@ __device__ __forceinline__ int frag_index(int i, int k)
 
 // ---------------------------------------------------------------------------------------------------- stream class
 template <bool fwd>
-__device__ __forceinline__ bool stream_task(const TrsmArgs &a, int tk, Ctl &c, double *smem)
+__device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, Ctl &c, double *smem)
 {
+    const int tk = pc.tk;
+    const bool owner = pc.p == pc.np - 1;
     const int tid = c.tid, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2, l15 = lane & 15, l4 = lane >> 4;
     const int T = a.T;
@@ -434,10 +467,18 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, int tk, Ctl &c, d
     };
     auto seg_ptr = [&](int q) { return a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD; };
     const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
-    const int nfold = tk < MS_F ? tk : MS_F, ns = tk - nfold;
-    auto stamp = [&](int i) { if (TRSM_DBG && a.dbg && tid == 0) a.dbg[16 * tk + i] = __builtin_amdgcn_s_memrealtime(); };
+    const int nfold = !owner ? 0 : (tk < MS_F ? tk : MS_F), ns = tk - (tk < MS_F ? tk : MS_F);
+    const int q0 = (int)((long)pc.p * ns / pc.np), q1 = (int)((long)(pc.p + 1) * ns / pc.np);   // this piece's dependencies
+    auto stamp = [&](int i) {
+        if (TRSM_DBG && a.dbg && tid == 0 && owner) {
+            if (i == 0) a.dbg[16 * tk + 12] = (unsigned long long)(q1 - q0);
+            a.dbg[16 * tk + i] = __builtin_amdgcn_s_memrealtime();
+            if (i == 1 || i == 2) a.dbg[16 * tk + 9 + i] = __builtin_amdgcn_s_memtime();   // shader clock of the streamed part
+        }
+    };
     stamp(0);
-    c.dbg_wait = (TRSM_DBG && a.dbg) ? a.dbg + 16 * tk + 8 : nullptr;
+    c.dbg_wait = (TRSM_DBG && a.dbg && owner) ? a.dbg + 16 * tk + 8 : nullptr;
+    c.qbase = q0;
     double4_t acc[2][2];
     // ---- M_f = op(inv) op(tile_{tk-f}), f = 1 .. nfold, 64 columns per pass, stored in fragment order (write-through)
     for (int f = 1; f <= nfold; ++f) {
@@ -465,13 +506,48 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, int tk, Ctl &c, d
     // tile (s, q) 128 columns on and segment q + 1 follows segment q; backward, tile (T-2-q, s) and segment T-2-q lie 128 rows
     // BEFORE their predecessors (256 rows back from where the eighth chunk ended).
     zero_acc(acc);
-    if (ns > 0) {
-        const OpStream oa{tile_ptr(0), (unsigned)a.ldl, fwd ? (long)MS_BK * (long)a.ldl : (long)MS_BK, fwd ? 0L : -2L * LEAF};
-        OpStream ob{seg_ptr(0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
+    if (q1 > q0) {
+        const OpStream oa{tile_ptr(q0), (unsigned)a.ldl, fwd ? (long)MS_BK * (long)a.ldl : (long)MS_BK, fwd ? 0L : -2L * LEAF};
+        OpStream ob{seg_ptr(q0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
         if (TRSM_DBG && a.fake_b) { ob.p0 = a.P + (size_t)(fwd ? 0 : T - 1) * LEAF * MS_YLD; ob.step = 0; ob.adj = 0; }   // experiment: every segment chunk from ONE cache-hot place (wrong results)
-        if (!stream_products<AT, false, true>(acc, ns, oa, ob, c, smem)) return false;
+        if (!stream_products<AT, false, true>(acc, q1 - q0, oa, ob, c, smem)) return false;
     }
     stamp(2);
+    // ---- a helper leaves its partial sum (value v of thread tid at [v][tid]: the owner's same thread takes it back) ...
+    if (!owner) {
+        double *xs = a.X + (size_t)(pc.x0 + pc.p) * XPART + tid;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) publish(xs + (size_t)((x * 2 + y) * 4 + r) * MS_T, acc[x][y][r]);
+        return true;
+    }
+    // ... and the owner adds them in piece order (8-byte granules: re-loaded until none is the all-ones pattern)
+    for (int p = 0; p + 1 < pc.np; ++p) {
+        const double *xs = a.X + (size_t)(pc.x0 + p) * XPART + tid;
+        unsigned long long bits[16];
+        unsigned long long t0 = 0;
+        unsigned it = 0;
+        bool ok = true;
+        for (;;) {
+            bool missing = false;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { bits[v] = load_bits_sc1(xs + (size_t)v * MS_T); missing |= bits[v] == UNPUBLISHED; }
+            if (!__builtin_amdgcn_ballot_w64(missing)) break;
+            if (it == 0) t0 = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_sleep(8);
+            if ((++it & 63u) == 0 && (gave_up(a.state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) { ok = false; break; }
+        }
+        if (!__syncthreads_and(ok)) { if (tid == 0) give_up(a.state); return false; }
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][y][r] += __longlong_as_double((long long)bits[(x * 2 + y) * 4 + r]);
+    }
     // ---- S = B_s - acc -> the hand-over image.  Every M_f store of this workgroup has been drained by now (each wave waits
     // for vmcnt(0) in front of every barrier of the products above; explicitly once more here): S is the chain's signal.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -610,14 +686,16 @@ template <bool fwd>
 __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
 {
     __shared__ double smem[A_STAGES * A_ELEMS + B_STAGES * B_ELEMS];
-    __shared__ int sh[4];
+    __shared__ int sh[8];
     const int tid = threadIdx.x;
     const bool chain = (int)blockIdx.x < a.nchain;
     const int ntasks = chain ? 4 * a.T : a.T;
-    Ctl c{a.state, a.ready, sh, 0, tid, nullptr};
+    Ctl c{a.state, a.ready, sh, 0, 0, tid, nullptr};
     for (;;) {
         if (tid == 0) {
-            sh[2] = atomicAdd(a.state + (chain ? 1 : 0), 1);
+            const int u = atomicAdd(a.state + (chain ? 1 : 0), 1);
+            sh[2] = u;
+            if (!chain) { const Piece pc = piece_of(u, a.piece); sh[2] = pc.tk; sh[4] = pc.p; sh[5] = pc.np; sh[6] = pc.x0; }
             // what is published by now may be read without polling; the acquire also drops every line this CU's L1 holds of
             // rows that have been published since it read them
             int v = 0x7fffffff;
@@ -629,12 +707,13 @@ __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
         __syncthreads();
         const int tk = sh[2];
         c.known = sh[3];
+        const Piece pc{tk, sh[4], sh[5], sh[6]};
         __syncthreads();
         if (tk >= ntasks || c.known < 0) return;
         if (chain) {
             chain_task<fwd>(a, tk, tid, smem);
         } else {
-            if (!stream_task<fwd>(a, tk, c, smem)) return;
+            if (!stream_task<fwd>(a, pc, c, smem)) return;
         }
         // (this barrier is not decoration: without one behind the one-lane regions at the end of a task hipcc folds them and the
         // one-lane ticket draw at the top of the loop into an exit of an inner loop that the other 511 threads keep running --
@@ -672,7 +751,7 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
     (void)hipMemset(a.dbg, 0, h.size() * 8);
     auto us = [&](int t, int i, int t2, int j) { return ((double)h[16 * t + i] - (double)h[16 * t2 + j]) * 0.01; };
     auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
-    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last;
+    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last, mhz;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int t = 0; t < T; ++t)
         for (int i = 0; i < 8; ++i)
@@ -681,19 +760,21 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
     for (int t = MS_F + 2; t < T; ++t) {
         step.push_back(us(t, 6, t - 1, 6));                  // publish to publish (quarter 0)
         prep.push_back(us(t, 1, t, 0));
-        tile.push_back(us(t, 2, t, 1) / (t - MS_F));
+        const double ntile = (double)h[16 * t + 12];
+        tile.push_back(us(t, 2, t, 1) / ntile);
         if (h[16 * t + 8] && h[16 * t + 9] > 16) { freetile.push_back(us(t, 8, t, 1) / (double)(h[16 * t + 9] - 1)); ++nwaited; }
-        else if (!h[16 * t + 8] && t - MS_F > 16) freetile.push_back(us(t, 2, t, 1) / (t - MS_F));
+        else if (!h[16 * t + 8] && ntile > 16) freetile.push_back(us(t, 2, t, 1) / ntile);
         spub.push_back(us(t, 3, t, 2));
+        if (h[16 * t + 2] > h[16 * t + 1] + 2000) mhz.push_back((double)(h[16 * t + 11] - h[16 * t + 10]) / (double)(h[16 * t + 2] - h[16 * t + 1]) * 100.0);
         slead.push_back(us(t - 1, 6, t, 3));                 // S handed over how long before the predecessor published
         zdone.push_back(us(t - 1, 6, t, 4));                 // Z formed how long before the predecessor published
         hop.push_back(us(t, 5, t - 1, 6));                   // predecessor published -> last product done here
         last.push_back(us(t, 6, t, 5));                      // publish
     }
     fprintf(stderr, "trsm %s T=%d: step %.2f us | fold %d tiles %.1f us | streamed tile %.2f us each, %.2f before the first wait (%d strips waited) | S out %.1f | "
-            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us\n",
+            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us | shader clock %.0f MHz\n",
             what, T, med(step), MS_F, med(prep), med(tile), med(freetile), nwaited, med(spub), med(slead), med(zdone), med(hop), med(last),
-            (double)(tmax - tmin) * 0.01);
+            (double)(tmax - tmin) * 0.01, med(mhz));
 }
 
 }  // namespace
@@ -705,10 +786,17 @@ bool trsm_strips_ok(int n, const double *L, size_t ldl)
            (size_t)LEAF * ldl < ((size_t)1 << 31);
 }
 
-// bytes of scratch: three images and the folded tiles
+// most tiles of L one stream task takes (piece_of); tunable "trsm_piece" (sgpr_probe_tune)
+static int piece_cap()
+{
+    const int v = (int)tune("trsm_piece", 128);
+    return v < 4 ? 4 : v;
+}
+
+// bytes of scratch: three images, the folded tiles and the partial sums of the strips streamed in pieces
 size_t trsm_strips_scratch(int n)
 {
-    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MS_F * MFRAG) * sizeof(double);
+    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MS_F * MFRAG + piece_partials(n / LEAF, piece_cap()) * XPART) * sizeof(double);
 }
 
 // B (n x nrhs, column-major, device) := L^-T L^-1 B, 64 columns per pass through the images; `state`: TRSM_STATE_INTS ints of
@@ -725,14 +813,17 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
     if (nchain > 4 * T) nchain = 4 * T;
     const int nstream = T < 256 - nchain ? T : 256 - nchain;
     const size_t img = (size_t)n * MS_YLD;
-    double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img;
+    double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img, *X = M + (size_t)T * MS_F * MFRAG;
+    const int piece = piece_cap();
+    const size_t xbytes = piece_partials(T, piece) * XPART * sizeof(double);
     for (int c0 = 0; c0 < nrhs; c0 += MS_NC) {
         const int nc = nrhs - c0 < MS_NC ? nrhs - c0 : MS_NC;
         hipLaunchKernelGGL(pack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, B + (size_t)c0 * ldb, ldb, I0);
         SGPR_CHECK_LAUNCH();
         SGPR_HIP(hipMemsetAsync(state, 0, TRSM_STATE_INTS * sizeof(int), st));
         SGPR_HIP(hipMemsetAsync(I1, 0xFF, 2 * img * sizeof(double), st));       // P and S of the forward solve
-        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
+        if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
+        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, X, piece, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
         const bool dbg = TRSM_DBG && getenv("SGPR_TRSM_DBG") != nullptr;
         if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * 16 * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * 16 * T); }
         hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);
@@ -741,6 +832,7 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
         // backward: in = the forward solution, out = the first image
         SGPR_HIP(hipMemsetAsync(I0, 0xFF, img * sizeof(double), st));
         SGPR_HIP(hipMemsetAsync(S, 0xFF, img * sizeof(double), st));
+        if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
         a.Bin = I1; a.P = I0;
         a.state = state + 4; a.ready = state + 12;
         hipLaunchKernelGGL(trsm_strips_kernel<false>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);

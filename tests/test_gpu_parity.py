@@ -656,6 +656,31 @@ def test_block_rhs_strip_solve(ops, n, nrhs):
     assert err.max() < 1e-11, (n, nrhs, err.max(), int(err.argmax()))
 
 
+@pytest.mark.parametrize("n,nrhs,piece", [(2304, 64, 4), (4096, 65, 8), (8192, 3, 16), (8192, 64, 7)])
+def test_block_rhs_strips_streamed_in_pieces(ops, n, nrhs, piece):
+    """Strips that stream more than `trsm_piece` tiles (128 in production: orders above 17 000) go out as several tickets whose
+    partial sums the last one adds up; here with a small cap, so that strips of 2 .. 15 pieces occur at test sizes.  Same
+    answer as LAPACK, and bit-identical from call to call (the pieces are added in a fixed order)."""
+    import scipy.linalg
+    from sympgpr_amd import _lib as L
+    probe = L.load_probe_library()
+    rng = np.random.default_rng(n + nrhs + piece)
+    L0 = np.tril(rng.standard_normal((n, n))) / np.sqrt(n)
+    L0[np.diag_indices(n)] = 1.0 + rng.uniform(0, 1, n)
+    B = rng.standard_normal((n, nrhs))
+    L.check(probe.sgpr_probe_tune(b"trsm_piece", float(piece)))
+    try:
+        X = ops.solve_cholesky(np.asfortranarray(L0), B)
+        X2 = ops.solve_cholesky(np.asfortranarray(L0), B)
+    finally:
+        L.check(probe.sgpr_probe_tune(b"trsm_piece", 128.0))
+    Xr = scipy.linalg.solve_triangular(L0.T, scipy.linalg.solve_triangular(L0, B, lower=True, check_finite=False),
+                                       lower=False, check_finite=False)
+    err = np.linalg.norm(X - Xr, axis=0) / np.linalg.norm(Xr, axis=0)
+    assert err.max() < 1e-11, (n, nrhs, piece, err.max(), int(err.argmax()))
+    assert np.array_equal(X, X2)
+
+
 # ---------------------------------------------------------------- d canonical pairs (BASELINE d = 2, 3)
 @pytest.mark.parametrize("fam,d,n,n0", [("A", 1, 37, 21), ("A", 2, 600, 70), ("C", 2, 33, 1025), ("A", 3, 130, 64),
                                         ("C", 3, 1, 5), ("B", 2, 100, 31), ("D", 2, 65, 130), ("D", 3, 20, 20),
