@@ -265,81 +265,37 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;      // lane 0 holds the sum
 }
 
-__global__ __launch_bounds__(ST) void mid_solve_kernel(const MidArgs a)
+// The solves of the batch: the right-hand sides padded to npad ...
+__global__ __launch_bounds__(256) void mid_rhs_kernel(const MidArgs a, double *r)
 {
-    __shared__ double r[16 * LEAF];        // the running right-hand side, then y, then alpha
-    __shared__ double tmp[2 * LEAF];
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.npad) r[(size_t)b * a.npad + i] = i < a.n ? a.z[(size_t)b * a.n + i] : 0.0;
+}
+// ... two launches of trsv.hip's strip solve over all problems (one workgroup per 128-row strip and problem, W x nbatch of
+// them; round 3 ran both solves of a problem in ONE workgroup: 64 problems of order 1024 kept 64 CUs busy for 0.6 ms, a third
+// of the whole call) ... and, per problem, nll = z.alpha / 2 + sum log L_ii (func.py:195) and alpha.
+__global__ __launch_bounds__(ST) void mid_finish_kernel(const MidArgs a, const double *r, const int *state, int *info)
+{
     __shared__ double red[ST / 64];
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int n = a.n, npad = a.npad, W = npad / (int)LEAF;
-    const size_t ld = (size_t)npad;
+    const int n = a.n;
+    const size_t ld = (size_t)a.npad;
     const double *A = a.A + (size_t)b * ld * ld;
-    const double *inv = a.inv + (size_t)b * W * LEAF * LEAF;
     const double *z = a.z + (size_t)b * n;
+    const double *al = r + (size_t)b * ld;
+    // a strip solve that gave up on a hand-off (state word 2 of either pass): an error of the call, not a result
+    if (a.info[b] == 0 && (state[8 * b + 2] | state[8 * b + 6]) != 0) {
+        if (t == 0) { info[b] = SOLVE_HANDOFF_TIMEOUT; a.nll[b] = __builtin_nan(""); }
+        return;
+    }
     if (a.info[b] != 0) {                  // not positive definite: the host turns info into NaN / +inf
         if (t == 0) a.nll[b] = __builtin_nan("");
         if (a.alpha)
             for (int i = t; i < n; i += ST) a.alpha[(size_t)b * n + i] = __builtin_nan("");
         return;
     }
-    for (int i = t; i < npad; i += ST) r[i] = i < n ? z[i] : 0.0;
-    __syncthreads();
-    // ---- y = L^-1 z, strip by strip: y_s = X_ss r_s, then r_t -= L_ts y_s for the rows below
-    for (int s = 0; s < W; ++s) {
-        const double *X = inv + (size_t)s * LEAF * LEAF;
-        {
-            // thread (i, h): half h of the k range of row i (lanes run over i: the loads of one k are contiguous)
-            const int i = t & 127, h = t >> 7;       // h = 0..3: quarters of k
-            double acc = 0.0;
-            const int k0 = h * 32, k1 = min(k0 + 32, i + 1);
-            for (int k = k0; k < k1; ++k) acc = __builtin_fma(X[i + k * LEAF], r[s * LEAF + k], acc);
-            // four partial sums per row: combine in a fixed order
-            for (int hh = 0; hh < 4; ++hh) {
-                if (h == hh) tmp[i] = hh == 0 ? acc : tmp[i] + acc;
-                __syncthreads();
-            }
-        }
-        if (t < (int)LEAF) r[s * LEAF + t] = tmp[t];
-        __syncthreads();
-        const int rows = npad - (s + 1) * (int)LEAF;
-        for (int q = t; q < rows; q += ST) {
-            const int row = (s + 1) * (int)LEAF + q;
-            const double *Ar = A + row + (size_t)s * LEAF * ld;
-            double acc0 = 0.0, acc1 = 0.0;
-            for (int k = 0; k < (int)LEAF; k += 2) {
-                acc0 = __builtin_fma(Ar[(size_t)k * ld], r[s * LEAF + k], acc0);
-                acc1 = __builtin_fma(Ar[(size_t)(k + 1) * ld], r[s * LEAF + k + 1], acc1);
-            }
-            r[row] -= acc0 + acc1;
-        }
-        __syncthreads();
-    }
-    // ---- alpha = L^-T y, from the last strip up: alpha_s = X_ss^T r_s, then r_j -= L(s, j)^T alpha_s for the columns left
-    for (int s = W - 1; s >= 0; --s) {
-        const double *X = inv + (size_t)s * LEAF * LEAF;
-        // column i of X_ss (entries k >= i) against r_s: one wave per column, lanes over k
-        for (int i = wave; i < (int)LEAF; i += ST / 64) {
-            double acc = 0.0;
-            for (int k = lane; k < (int)LEAF; k += 64)
-                if (k >= i) acc = __builtin_fma(X[k + i * LEAF], r[s * LEAF + k], acc);
-            acc = wave_sum(acc);
-            if (lane == 0) tmp[i] = acc;
-        }
-        __syncthreads();
-        if (t < (int)LEAF) r[s * LEAF + t] = tmp[t];
-        __syncthreads();
-        const int cols = s * (int)LEAF;
-        for (int j = wave; j < cols; j += ST / 64) {
-            const double *Ac = A + (size_t)s * LEAF + (size_t)j * ld;      // rows of strip s in column j: contiguous
-            double acc = __builtin_fma(Ac[lane], r[s * LEAF + lane], Ac[lane + 64] * r[s * LEAF + lane + 64]);
-            acc = wave_sum(acc);
-            if (lane == 0) r[j] -= acc;
-        }
-        __syncthreads();
-    }
-    // ---- nll = z.alpha / 2 + sum log L_ii  (func.py:195)
     double q = 0.0;
-    for (int i = t; i < n; i += ST) q += 0.5 * z[i] * r[i] + log(A[i + i * ld]);
+    for (int i = t; i < n; i += ST) q += 0.5 * z[i] * al[i] + log(A[i + i * ld]);
     q = wave_sum(q);
     if (lane == 0) red[wave] = q;
     __syncthreads();
@@ -349,7 +305,7 @@ __global__ __launch_bounds__(ST) void mid_solve_kernel(const MidArgs a)
         a.nll[b] = v;
     }
     if (a.alpha)
-        for (int i = t; i < n; i += ST) a.alpha[(size_t)b * n + i] = r[i];
+        for (int i = t; i < n; i += ST) a.alpha[(size_t)b * n + i] = al[i];
 }
 
 // Device + pinned-host staging of one calling thread, grown on demand and kept: a call is then one H2D copy,
@@ -414,8 +370,10 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
     const size_t o_x = 0, o_y = o_x + up256(C * npts * 8), o_z = o_y + up256(C * npts * 8), o_kc = o_z + up256(C * n * 8),
                  o_no = o_kc + up256(C * sizeof(KConst)), in_bytes = o_no + up256(C * 8);
     const size_t o_al = 0, o_nll = o_al + up256(C * n * 8), o_info = o_nll + up256(C * 8), out_bytes = o_info + up256(C * sizeof(int));
+    // (+ the solves: right-hand sides / solution padded to npad, the two publication buffers, 8 state words per problem)
     const size_t o_A = 0, o_inv = o_A + up256(C * img), o_fl = o_inv + up256(C * invb), o_fl2 = o_fl + up256(potrf_batch_flag_bytes(chunk)),
-                 scr_bytes = o_fl2 + up256(potrf_batch_flag_bytes(chunk));
+                 o_r = o_fl2 + up256(potrf_batch_flag_bytes(chunk)), o_pub = o_r + up256(C * npad * 8), o_st = o_pub + up256(2 * C * npad * 8),
+                 scr_bytes = o_st + up256(C * 8 * sizeof(int));
     Arena &ar = t_arena;
     int rc = ar.reserve(in_bytes + out_bytes + scr_bytes, in_bytes + out_bytes);
     if (rc) return rc;
@@ -474,7 +432,20 @@ int fit_batch_mid(int family, int nbatch, int npts, int n, int reg, const double
                                         reinterpret_cast<int *>(dscr + o_fl2), dinfo, st)))
                 return rc;
         }
-        hipLaunchKernelGGL(mid_solve_kernel, dim3(nb), dim3(ST), 0, st, a);
+        // y = L^-1 z, alpha = L^-T y for every problem: the strip solve of trsv.hip, W x nb workgroups per launch
+        double *dr = reinterpret_cast<double *>(dscr + o_r), *dpub = reinterpret_cast<double *>(dscr + o_pub);
+        int *dst = reinterpret_cast<int *>(dscr + o_st);
+        SGPR_HIP(hipMemsetAsync(dst, 0, B * 8 * sizeof(int), st));
+        SGPR_HIP(hipMemsetAsync(dpub, 0xFF, 2 * B * npad * 8, st));
+        hipLaunchKernelGGL(mid_rhs_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)nb), dim3(256), 0, st, a, dr);
+        SGPR_CHECK_LAUNCH();
+        if ((rc = trsv_strips_batch(nb, npad, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF, dr, (size_t)npad, 0,
+                                    dst, 8, dpub, st)))
+            return rc;
+        if ((rc = trsv_strips_batch(nb, npad, dA, (size_t)npad * npad, (size_t)npad, dinv, (size_t)W * LEAF * LEAF, dr, (size_t)npad, 1,
+                                    dst + 4, 8, dpub + B * npad, st)))
+            return rc;
+        hipLaunchKernelGGL(mid_finish_kernel, dim3(nb), dim3(ST), 0, st, a, (const double *)dr, (const int *)dst, dinfo);
         SGPR_CHECK_LAUNCH();
         const size_t from = alpha ? 0 : o_nll;
         SGPR_HIP(hipMemcpyAsync(hout + from, dout + from, out_bytes - from, hipMemcpyDeviceToHost, st));

@@ -96,10 +96,12 @@ constexpr int LEAF = 128;  // order of the diagonal block factored in LDS by one
 // value left in *dinfo when a hand-off inside the persistent panel kernel timed out (a bug or a
 // device problem, never a property of the matrix); info_status() turns it into SGPR_E_HIP
 constexpr int POTRF_HANDOFF_TIMEOUT = -1000001;
+constexpr int SOLVE_HANDOFF_TIMEOUT = -1000002;   // the same for the strip solves of a batch (batch.hip)
 inline int info_status(int info)
 {
     if (info >= 0) return info;
-    set_error(info == POTRF_HANDOFF_TIMEOUT ? "potrf: a hand-off inside the panel kernel timed out" : "potrf: internal error");
+    set_error(info == POTRF_HANDOFF_TIMEOUT ? "potrf: a hand-off inside the panel kernel timed out"
+              : info == SOLVE_HANDOFF_TIMEOUT ? "solve: a hand-off between the strips of a triangular solve timed out" : "potrf: internal error");
     return SGPR_E_HIP;
 }
 size_t potrf_workspace(int n);
@@ -135,6 +137,9 @@ int leaf_inverses(int n, const double *L, size_t ldl, void *work, int *dinfo, hi
 bool trsv_strips_ok(int n, const double *L, size_t ldl);
 int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state /* 4 ints, zero */,
                 double *pub /* n doubles, all bytes 0xFF */, hipStream_t st);
+// `nbatch` independent systems of one order in one launch: problem p at L + p sL, inv + p sInv, b / pub + p sB, state + p sState
+int trsv_strips_batch(int nbatch, int n, const double *L, size_t sL, size_t ldl, const double *inv, size_t sInv, double *b, size_t sB,
+                      int trans, int *state, int sState, double *pub, hipStream_t st);
 
 // ---- trsm.hip : triangular solves with a block of right-hand sides, one launch per solve (strips + progress counter)
 constexpr int TRSM_YLD = 80;                                      // row stride of the right-hand-side images [k][64 + 16]

@@ -54,6 +54,9 @@ struct TrsvArgs {
     int *state;            // [0] ticket, [1] ready (strips finished, in ticket order), [2] timeout flag
     int trans;
     unsigned long long *dbg;
+    // a batch of independent systems of the same order, problem blockIdx.y: element strides of L, inv, b and pub; ints of state
+    size_t sL, sInv, sB;
+    int sState;
 };
 
 __device__ __forceinline__ void store_sc1(double *p, double v)
@@ -95,8 +98,13 @@ __device__ __forceinline__ int col_of(int e, int l4) { return 16 * (e >> 2) + 4 
 __device__ __forceinline__ int colx_of(int e, int l4) { return 16 * (e >> 2) + 4 * l4 + (e & 3); }
 
 template <bool fwd>
-__global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a)
+__global__ __launch_bounds__(TS_T) void trsv_strips_kernel(const TrsvArgs a_in)
 {
+    TrsvArgs a = a_in;
+    {
+        const size_t pb = blockIdx.y;       // (tickets, progress and give-up words are per problem: a workgroup waits for its own system only)
+        a.L += pb * a.sL; a.inv += pb * a.sInv; a.b += pb * a.sB; a.pub += pb * a.sB; a.state += pb * a.sState;
+    }
     __shared__ double stg[LEAF * SLD];       // the last tile of the strip, staged for the matrix cores; then M, parked
     __shared__ double vec[2][LEAF];          // the segment of the solution a tile is multiplied with
     __shared__ double red[TS_W][LEAF];       // cross-wave partial sums (forward)
@@ -346,14 +354,23 @@ bool trsv_strips_ok(int n, const double *L, size_t ldl)
 int trsv_strips(int n, const double *L, size_t ldl, const double *inv, double *b, int trans, int *state, double *pub,
                 hipStream_t st)
 {
-    if (n <= 0) return 0;
-    if (!trsv_strips_ok(n, L, ldl)) { set_error("trsv_strips: shape not supported"); return SGPR_E_ARG; }
-    TrsvArgs a{n / LEAF, L, ldl, inv, b, pub, state, trans, nullptr};
-    const bool dbg = TRSV_DBG && getenv("SGPR_TRSV_DBG") != nullptr;
+    return trsv_strips_batch(1, n, L, 0, ldl, inv, 0, b, 0, trans, state, 0, pub, st);
+}
+
+// The same for `nbatch` independent systems of one order in ONE launch (batch.hip: the solves of a batch of mid-size fits):
+// problem p has its factor at L + p sL, its leaf inverses at inv + p sInv, its right-hand side at b + p sB, its publication
+// buffer at pub + p sB and its state words at state + p sState (zero / all-ones on entry as above).
+int trsv_strips_batch(int nbatch, int n, const double *L, size_t sL, size_t ldl, const double *inv, size_t sInv, double *b, size_t sB,
+                      int trans, int *state, int sState, double *pub, hipStream_t st)
+{
+    if (n <= 0 || nbatch <= 0) return 0;
+    if (!trsv_strips_ok(n, L, ldl) || (sL & 1) || nbatch > 65535) { set_error("trsv_strips: shape not supported"); return SGPR_E_ARG; }
+    TrsvArgs a{n / LEAF, L, ldl, inv, b, pub, state, trans, nullptr, sL, sInv, sB, sState};
+    const bool dbg = TRSV_DBG && nbatch == 1 && getenv("SGPR_TRSV_DBG") != nullptr;
     if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * 4 * a.T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * 4 * a.T); }
     const int grid = a.T < 256 ? a.T : 256;
-    if (trans) hipLaunchKernelGGL(trsv_strips_kernel<false>, dim3(grid), dim3(TS_T), 0, st, a);
-    else       hipLaunchKernelGGL(trsv_strips_kernel<true>, dim3(grid), dim3(TS_T), 0, st, a);
+    if (trans) hipLaunchKernelGGL(trsv_strips_kernel<false>, dim3(grid, nbatch), dim3(TS_T), 0, st, a);
+    else       hipLaunchKernelGGL(trsv_strips_kernel<true>, dim3(grid, nbatch), dim3(TS_T), 0, st, a);
     SGPR_CHECK_LAUNCH();
     if (dbg) {
         (void)hipStreamSynchronize(st);
