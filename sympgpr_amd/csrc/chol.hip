@@ -803,6 +803,7 @@ struct PanelBatch {
     int W, nbatch;          // diagonal strips of this panel (its width / 128)
     int R;                  // row strips from the panel's first row to the end of the matrix (>= W): W .. R-1 are solved against it
     int k0;                 // first row / column of the panel inside its problem (a multiple of 128)
+    int G;                  // workgroups per problem: W for the diagonal strips + G - W that share the R - W strips below
 };
 
 __global__ __launch_bounds__(LT) void panel_batch_kernel(const PanelBatch q)
@@ -813,11 +814,11 @@ __global__ __launch_bounds__(LT) void panel_batch_kernel(const PanelBatch q)
     __syncthreads();
     const int t = sh[0];
     __syncthreads();
-    const int p = t / q.R, g = t - p * q.R;      // (diagonal strips 0 .. W-1 hold the smallest tickets of their problem)
+    const int p = t / q.G, g = t - p * q.G;      // (diagonal strips 0 .. W-1 hold the smallest tickets of their problem)
     if (p >= q.nbatch) return;
     PanelArgs a{};
     a.P = q.A + (size_t)p * q.stride_a + (size_t)q.k0 + (size_t)q.k0 * q.lda; a.lda = q.lda;
-    a.W = q.W; a.R = a.G = q.R;
+    a.W = q.W; a.R = q.R; a.G = q.G;
     a.inv = q.inv + (size_t)p * q.stride_inv + (size_t)(q.k0 / (int)LEAF) * LEAF * LEAF;
     a.dinfo = q.info + p; a.goff = q.k0;
     a.flags = q.flags + (size_t)p * PFLAG_STRIDE;
@@ -1536,8 +1537,11 @@ int potrf_batch_panel(int nbatch, int npad, int k0, int Wd, double *A, size_t st
         return SGPR_E_ARG;
     }
     SGPR_HIP(hipMemsetAsync(flags, 0, potrf_batch_flag_bytes(nbatch), st));
-    PanelBatch q{A, stride_a, lda, inv, stride_inv, flags, info, flags + (size_t)nbatch * PFLAG_STRIDE, Wd, nbatch, R, k0};
-    hipLaunchKernelGGL(panel_batch_kernel, dim3((unsigned)(nbatch * R)), dim3(LT), 0, st, q);
+    // workgroups for the strips below the diagonal block: tunable "batch_below" (sgpr_probe_tune), default one per strip
+    const int below_max = (int)tune("batch_below", 0);
+    const int below = R - Wd <= 0 ? 0 : (below_max > 0 && below_max < R - Wd ? below_max : R - Wd);
+    PanelBatch q{A, stride_a, lda, inv, stride_inv, flags, info, flags + (size_t)nbatch * PFLAG_STRIDE, Wd, nbatch, R, k0, Wd + below};
+    hipLaunchKernelGGL(panel_batch_kernel, dim3((unsigned)(nbatch * (Wd + below))), dim3(LT), 0, st, q);
     SGPR_CHECK_LAUNCH();
     return 0;
 }

@@ -110,6 +110,7 @@ constexpr bool TRSM_DBG = true;
 constexpr bool TRSM_DBG = false;   // per-strip time stamps (experiments: make EXTRA=-DSGPR_TRSM_DBG, SGPR_TRSM_DBG=1)
 #endif
 
+constexpr int DBGW = 32;                      // debug builds: stamp words per strip
 constexpr unsigned long long UNPUBLISHED = ~0ull;
 
 // A stream ticket = one PIECE of a strip.  Strip tk streams ns = tk - MS_F tiles; dealt whole, the last tickets are the longest
@@ -130,6 +131,13 @@ __host__ __device__ inline Piece piece_of(int u, int C)
     while (u >= C * (m + 1)) { u -= C * (m + 1); x += C * m; ++m; }
     const int j = u / (m + 1);
     return Piece{g0 + (m - 1) * C + j, u % (m + 1), m + 1, x + j * m};
+}
+// stream tickets of a solve with T strips (host: sizes the grid)
+inline size_t piece_tickets(int T, int C)
+{
+    size_t x = 0;
+    for (int tk = 0; tk < T; ++tk) x += tk <= TRSM_FOLD + C ? 1 : (size_t)((tk - TRSM_FOLD + C - 1) / C);
+    return x;
 }
 // partial sums of a solve with T strips (host: sizes the scratch)
 inline size_t piece_partials(int T, int C)
@@ -471,13 +479,13 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
     const int q0 = (int)((long)pc.p * ns / pc.np), q1 = (int)((long)(pc.p + 1) * ns / pc.np);   // this piece's dependencies
     auto stamp = [&](int i) {
         if (TRSM_DBG && a.dbg && tid == 0 && owner) {
-            if (i == 0) a.dbg[16 * tk + 12] = (unsigned long long)(q1 - q0);
-            a.dbg[16 * tk + i] = __builtin_amdgcn_s_memrealtime();
-            if (i == 1 || i == 2) a.dbg[16 * tk + 9 + i] = __builtin_amdgcn_s_memtime();   // shader clock of the streamed part
+            if (i == 0) a.dbg[DBGW * tk + 12] = (unsigned long long)(q1 - q0);
+            a.dbg[DBGW * tk + i] = __builtin_amdgcn_s_memrealtime();
+            if (i == 1 || i == 2) a.dbg[DBGW * tk + 9 + i] = __builtin_amdgcn_s_memtime();   // shader clock of the streamed part
         }
     };
     stamp(0);
-    c.dbg_wait = (TRSM_DBG && a.dbg && owner) ? a.dbg + 16 * tk + 8 : nullptr;
+    c.dbg_wait = (TRSM_DBG && a.dbg && owner) ? a.dbg + DBGW * tk + 8 : nullptr;
     c.qbase = q0;
     double4_t acc[2][2];
     // ---- M_f = op(inv) op(tile_{tk-f}), f = 1 .. nfold, 64 columns per pass, stored in fragment order (write-through)
@@ -505,11 +513,23 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
     // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q.  Both operands are linear streams: forward, tile (s, q + 1) follows
     // tile (s, q) 128 columns on and segment q + 1 follows segment q; backward, tile (T-2-q, s) and segment T-2-q lie 128 rows
     // BEFORE their predecessors (256 rows back from where the eighth chunk ended).
+    // The owner's sums start at -B_s (fetched here, under the stream): S = -(sum - B_s) then goes out the moment the last
+    // product is done -- fetching B_s behind the stream held the hand-over back by ~5 us, on the cycle that bounds the launch at
+    // orders where the chain does (stream tail + chain task, spread over F + 1 strips).
     zero_acc(acc);
+    if (owner) {
+        const double *bs = a.Bin + (size_t)s * LEAF * MS_YLD;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[x][y][r] = -bs[row_of(x, r) * MS_YLD + col_of(y)];
+    }
     if (q1 > q0) {
         const OpStream oa{tile_ptr(q0), (unsigned)a.ldl, fwd ? (long)MS_BK * (long)a.ldl : (long)MS_BK, fwd ? 0L : -2L * LEAF};
         OpStream ob{seg_ptr(q0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
-        if (TRSM_DBG && a.fake_b) { ob.p0 = a.P + (size_t)(fwd ? 0 : T - 1) * LEAF * MS_YLD; ob.step = 0; ob.adj = 0; }   // experiment: every segment chunk from ONE cache-hot place (wrong results)
+        if (TRSM_DBG && a.fake_b == 1) { ob.p0 = a.P + (size_t)(fwd ? 0 : T - 1) * LEAF * MS_YLD; ob.step = 0; ob.adj = 0; }   // experiment: every segment chunk from ONE cache-hot place (wrong results)
         if (!stream_products<AT, false, true>(acc, q1 - q0, oa, ob, c, smem)) return false;
     }
     stamp(2);
@@ -548,11 +568,10 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[x][y][r] += __longlong_as_double((long long)bits[(x * 2 + y) * 4 + r]);
     }
-    // ---- S = B_s - acc -> the hand-over image.  Every M_f store of this workgroup has been drained by now (each wave waits
+    // ---- S = -acc = B_s - sums -> the hand-over image.  Every M_f store of this workgroup has been drained by now (each wave waits
     // for vmcnt(0) in front of every barrier of the products above; explicitly once more here): S is the chain's signal.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const double *bs = a.Bin + (size_t)s * LEAF * MS_YLD;
     double *ss = a.S + (size_t)s * LEAF * MS_YLD;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -561,7 +580,7 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = row_of(x, r) * MS_YLD + col_of(y);
-                publish(ss + o, bs[o] - acc[x][y][r]);
+                publish(ss + o, -acc[x][y][r]);
             }
     stamp(3);
     return true;
@@ -572,31 +591,44 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
 // `seg` = &image[first row of the segment][16 c].  Every wave fetches ITS 16 rows of the quarter (4 elements per lane, the
 // ones wave w of the producer published), polling until none is the all-ones pattern, and the eight waves share them through
 // LDS behind one barrier: a wave that pulls the whole 16 KB quarter by itself -- the first form -- pays ~4 us of its own memory
-// queue per product (MI355X_MICROARCH.md, handoff-payload), 2 KB cost one round trip.  Called by all waves alike.
-__device__ __forceinline__ bool quarter_product(double4_t &acc, const double (&af)[32], const double *seg, double *qbuf, int *state,
-                                                int wave, int l15, int l4)
+// queue per product (MI355X_MICROARCH.md, handoff-payload), 2 KB cost one round trip.
+// In three parts, so that the round trip for the NEXT product's rows runs under this product's MFMAs (a chain task is F + 1
+// products in a row, and its length is on the cycle that bounds the launch at chain-bound orders):
+//   quarter_ask (loads only) ... quarter_have (waits, asks again until the rows are there) ... quarter_multiply.
+struct QuarterRows { unsigned long long bits[4]; };
+__device__ __forceinline__ void quarter_ask(QuarterRows &q, const double *seg, int wave, int l15, int l4)
 {
-    bool ok = true;
     const double *src = seg + (size_t)(16 * wave + l4) * MS_YLD + l15;          // element r: row 16 w + 4 r + l4
-    unsigned long long bits[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q.bits[r] = load_bits_sc1(src + (size_t)(4 * r) * MS_YLD);
+}
+__device__ __forceinline__ bool quarter_have(QuarterRows &q, const double *seg, int *state, int wave, int l15, int l4)
+{
     unsigned long long t0 = 0;
     unsigned it = 0;
     for (;;) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bits[r] = load_bits_sc1(src + (size_t)(4 * r) * MS_YLD);
-        const bool missing = bits[0] == UNPUBLISHED || bits[1] == UNPUBLISHED || bits[2] == UNPUBLISHED || bits[3] == UNPUBLISHED;
-        if (!__builtin_amdgcn_ballot_w64(missing)) break;
+        const bool missing = q.bits[0] == UNPUBLISHED || q.bits[1] == UNPUBLISHED || q.bits[2] == UNPUBLISHED || q.bits[3] == UNPUBLISHED;
+        if (!__builtin_amdgcn_ballot_w64(missing)) return true;
         if (it == 0) t0 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_sleep(1);
-        if ((++it & 127u) == 0 && (gave_up(state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) { ok = false; break; }
+        if ((++it & 127u) == 0 && (gave_up(state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) return false;
+        quarter_ask(q, seg, wave, l15, l4);
     }
+}
+// `under`: called once every wave's rows are in LDS and the first fragment reads are out -- the place for the next product's loads
+template <typename Under>
+__device__ __forceinline__ void quarter_multiply(double4_t &acc, const double (&af)[32], const QuarterRows &q, double *qbuf, int wave,
+                                                 int l15, int l4, Under &&under, unsigned long long *st = nullptr)
+{
+    if (TRSM_DBG && st) st[0] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) qbuf[(16 * wave + 4 * r + l4) * 16 + l15] = __longlong_as_double((long long)bits[r]);
+    for (int r = 0; r < 4; ++r) qbuf[(16 * wave + 4 * r + l4) * 16 + l15] = __longlong_as_double((long long)q.bits[r]);
     // (a bare barrier behind the LDS writes: __syncthreads() would also wait for the fragments of the next M_f, which are
     // meant to arrive under this product)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if (TRSM_DBG && st) st[1] = __builtin_amdgcn_s_memrealtime();
     // fragments b[kk] = B[4 kk + l4][l15]: rows of 16 doubles, two consecutive rows cover the 64 banks
     const unsigned ab = lds_addr(qbuf + l4 * 16 + l15);
     double b[32];
@@ -612,6 +644,8 @@ __device__ __forceinline__ bool quarter_product(double4_t &acc, const double (&a
     __builtin_amdgcn_sched_barrier(0)
     // eight reads ahead of the MFMAs (the LDS counter holds 15)
     TRSM_RB8(0);
+    under();
+    __builtin_amdgcn_sched_barrier(0);
     TRSM_RB8(8);  TRSM_LGKM_WAIT(8); TRSM_MM8(0);
     TRSM_RB8(16); TRSM_LGKM_WAIT(8); TRSM_MM8(8);
     TRSM_RB8(24); TRSM_LGKM_WAIT(8); TRSM_MM8(16);
@@ -620,7 +654,7 @@ __device__ __forceinline__ bool quarter_product(double4_t &acc, const double (&a
 #undef TRSM_RB8
 #undef TRSM_MM8
     acc += e + o;
-    return ok;
+    if (TRSM_DBG && st) st[2] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <bool fwd>
@@ -632,7 +666,7 @@ __device__ __forceinline__ void chain_task(const TrsmArgs &a, int u, int tid, do
     const int s = fwd ? tk : T - 1 - tk;
     const int nfold = tk < MS_F ? tk : MS_F;
     const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
-    auto stamp = [&](int i) { if (TRSM_DBG && a.dbg && tid == 0 && cq == 0) a.dbg[16 * tk + i] = __builtin_amdgcn_s_memrealtime(); };
+    auto stamp = [&](int i) { if (TRSM_DBG && a.dbg && tid == 0 && cq == 0) a.dbg[DBGW * tk + i] = __builtin_amdgcn_s_memrealtime(); };
     // two LDS images of a quarter segment, used in turn: product n + 2 writes the image product n read, and every wave has
     // passed the barrier of product n + 1 -- behind its reads of product n -- by then
     double *const qb0 = smem, *const qb1 = smem + LEAF * 16;
@@ -650,24 +684,38 @@ __device__ __forceinline__ void chain_task(const TrsmArgs &a, int u, int tid, do
     // drained before S went out, and this CU has never read them)
     double2_t an[16];
     auto load_m = [&](int f) {
-        const double *Mf = a.M + ((size_t)s * MS_F + (f - 1)) * MFRAG + ((size_t)(wave * 16) * 64 + lane) * 2;
+        const double *Mf = a.M + ((size_t)((TRSM_DBG && a.fake_b == 2) ? 0 : s) * MS_F + (f - 1)) * MFRAG + ((size_t)(wave * 16) * 64 + lane) * 2;   // (experiment 2: every strip reads strip 0's folded tiles -- cache-hot, wrong results)
 #pragma unroll
         for (int p = 0; p < 16; ++p) an[p] = *reinterpret_cast<const double2_t *>(Mf + (size_t)p * 128);
     };
+    auto seg_of = [&](int f) {                                // the segment M_f multiplies: the one published (tk - f)-th
+        const int q = tk - f;
+        return a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD + 16 * cq;
+    };
+    const double *sseg = a.S + (size_t)s * LEAF * MS_YLD + 16 * cq;
+    QuarterRows rows, next;
     double4_t z = double4_t{0.0, 0.0, 0.0, 0.0};
-    ok &= quarter_product(z, af, a.S + (size_t)s * LEAF * MS_YLD + 16 * cq, (nq++ & 1) ? qb1 : qb0, a.state, wave, l15, l4);
+    quarter_ask(rows, sseg, wave, l15, l4);
+    ok &= quarter_have(rows, sseg, a.state, wave, l15, l4);
     if (nfold > 0) load_m(nfold);        // (behind the wait for S: M_f is complete once S is there)
+    quarter_multiply(z, af, rows, (nq++ & 1) ? qb1 : qb0, wave, l15, l4, [&]() { if (nfold > 0) quarter_ask(next, seg_of(nfold), wave, l15, l4); });
     stamp(4);
     for (int f = nfold; f >= 1; --f) {
+        if (f == 2) stamp(16);
 #pragma unroll
         for (int p = 0; p < 16; ++p) { af[2 * p] = an[p].x; af[2 * p + 1] = an[p].y; }
+        if (TRSM_DBG && a.dbg && f == 2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); stamp(17); }    // (the four row loads of `next` are younger)
         if (f > 1) load_m(f - 1);
-        const int q = tk - f;                                  // dependency q: the segment of the strip published q-th
-        const double *seg = a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD + 16 * cq;
+        if (f == 2) stamp(18);
+        ok &= quarter_have(next, seg_of(f), a.state, wave, l15, l4);
+        if (f == 2) stamp(19);
+        rows = next;
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
-        ok &= quarter_product(acc, af, seg, (nq++ & 1) ? qb1 : qb0, a.state, wave, l15, l4);
+        quarter_multiply(acc, af, rows, (nq++ & 1) ? qb1 : qb0, wave, l15, l4, [&]() { if (f > 1) quarter_ask(next, seg_of(f - 1), wave, l15, l4); },
+                         (TRSM_DBG && a.dbg && tid == 0 && cq == 0 && f <= 2) ? a.dbg + DBGW * tk + (f == 1 ? 13 : 21) : nullptr);
         if (f == 1) stamp(5);
         z -= acc;
+        if (f == 2) stamp(20);
     }
     // publish: element (row 16 w + 4 r + l4, column 16 cq + l15)
     double *ps = a.P + (size_t)s * LEAF * MS_YLD + (size_t)(16 * wave + l4) * MS_YLD + 16 * cq + l15;
@@ -746,35 +794,42 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
 {
     (void)hipStreamSynchronize(st);
     const int T = a.T;
-    std::vector<unsigned long long> h(16 * (size_t)T);
+    std::vector<unsigned long long> h(DBGW * (size_t)T);
     (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
     (void)hipMemset(a.dbg, 0, h.size() * 8);
-    auto us = [&](int t, int i, int t2, int j) { return ((double)h[16 * t + i] - (double)h[16 * t2 + j]) * 0.01; };
+    auto us = [&](int t, int i, int t2, int j) { return ((double)h[DBGW * t + i] - (double)h[DBGW * t2 + j]) * 0.01; };
     auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
-    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last, mhz;
+    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last, mhz, c0, c1, c2, p0, p1, p2, p3, p4, p5, p6;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int t = 0; t < T; ++t)
         for (int i = 0; i < 8; ++i)
-            if (h[16 * t + i]) { tmin = std::min(tmin, h[16 * t + i]); tmax = std::max(tmax, h[16 * t + i]); }
+            if (h[DBGW * t + i]) { tmin = std::min(tmin, h[DBGW * t + i]); tmax = std::max(tmax, h[DBGW * t + i]); }
     int nwaited = 0;
     for (int t = MS_F + 2; t < T; ++t) {
         step.push_back(us(t, 6, t - 1, 6));                  // publish to publish (quarter 0)
         prep.push_back(us(t, 1, t, 0));
-        const double ntile = (double)h[16 * t + 12];
+        const double ntile = (double)h[DBGW * t + 12];
         tile.push_back(us(t, 2, t, 1) / ntile);
-        if (h[16 * t + 8] && h[16 * t + 9] > 16) { freetile.push_back(us(t, 8, t, 1) / (double)(h[16 * t + 9] - 1)); ++nwaited; }
-        else if (!h[16 * t + 8] && ntile > 16) freetile.push_back(us(t, 2, t, 1) / ntile);
+        if (h[DBGW * t + 8] && h[DBGW * t + 9] > 16) { freetile.push_back(us(t, 8, t, 1) / (double)(h[DBGW * t + 9] - 1)); ++nwaited; }
+        else if (!h[DBGW * t + 8] && ntile > 16) freetile.push_back(us(t, 2, t, 1) / ntile);
         spub.push_back(us(t, 3, t, 2));
-        if (h[16 * t + 2] > h[16 * t + 1] + 2000) mhz.push_back((double)(h[16 * t + 11] - h[16 * t + 10]) / (double)(h[16 * t + 2] - h[16 * t + 1]) * 100.0);
+        if (h[DBGW * t + 2] > h[DBGW * t + 1] + 2000) mhz.push_back((double)(h[DBGW * t + 11] - h[DBGW * t + 10]) / (double)(h[DBGW * t + 2] - h[DBGW * t + 1]) * 100.0);
         slead.push_back(us(t - 1, 6, t, 3));                 // S handed over how long before the predecessor published
         zdone.push_back(us(t - 1, 6, t, 4));                 // Z formed how long before the predecessor published
         hop.push_back(us(t, 5, t - 1, 6));                   // predecessor published -> last product done here
+        c0.push_back(us(t, 13, t - 1, 6));                   // ... -> wave 0 has its rows of the predecessor's segment
+        c1.push_back(us(t, 14, t, 13));                      // ... -> every wave has, LDS image complete
+        c2.push_back(us(t, 15, t, 14));
+        // the product before the last one, phase by phase (wave 0 of quarter 0)
+        p0.push_back(us(t, 17, t, 16)); p1.push_back(us(t, 18, t, 17)); p2.push_back(us(t, 19, t, 18)); p3.push_back(us(t, 21, t, 19));
+        p4.push_back(us(t, 22, t, 21)); p5.push_back(us(t, 23, t, 22)); p6.push_back(us(t, 20, t, 23));                      // ... -> fragments read, 32 MFMAs done
         last.push_back(us(t, 6, t, 5));                      // publish
     }
     fprintf(stderr, "trsm %s T=%d: step %.2f us | fold %d tiles %.1f us | streamed tile %.2f us each, %.2f before the first wait (%d strips waited) | S out %.1f | "
-            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us | shader clock %.0f MHz\n",
+            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us | shader clock %.0f MHz | last product: published -> wave 0 has it %.2f, -> all waves %.2f, -> MFMAs done %.2f | product 2 by phase: M_2 landed %.2f, M_1 asked for %.2f, rows there %.2f, into the product %.2f, "
+            "LDS + barrier %.2f, reads + MFMAs %.2f, out %.2f\n",
             what, T, med(step), MS_F, med(prep), med(tile), med(freetile), nwaited, med(spub), med(slead), med(zdone), med(hop), med(last),
-            (double)(tmax - tmin) * 0.01, med(mhz));
+            (double)(tmax - tmin) * 0.01, med(mhz), med(c0), med(c1), med(c2), med(p0), med(p1), med(p2), med(p3), med(p4), med(p5), med(p6));
 }
 
 }  // namespace
@@ -787,16 +842,19 @@ bool trsm_strips_ok(int n, const double *L, size_t ldl)
 }
 
 // most tiles of L one stream task takes (piece_of); tunable "trsm_piece" (sgpr_probe_tune)
-static int piece_cap()
+// Default: 128 (n = 65 536 ... 98 304: 64 ... 256 within 3 %); 16 up to 128 strips, where every stream task sits at the chain's
+// frontier for its whole life and shorter pieces put the idle half of the chip to work (n = 8192 / 16 384: 1.32 -> 1.27 /
+// 2.46 -> 2.39 ms; at 256 strips 16 is slower than 128: 5.2 against 5.0 ms).
+static int piece_cap(int T)
 {
-    const int v = (int)tune("trsm_piece", 128);
-    return v < 4 ? 4 : v;
+    const int v = (int)tune("trsm_piece", 0);
+    return v <= 0 ? (T <= 128 ? 16 : 128) : (v < 4 ? 4 : v);
 }
 
 // bytes of scratch: three images, the folded tiles and the partial sums of the strips streamed in pieces
 size_t trsm_strips_scratch(int n)
 {
-    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MS_F * MFRAG + piece_partials(n / LEAF, piece_cap()) * XPART) * sizeof(double);
+    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MS_F * MFRAG + piece_partials(n / LEAF, piece_cap(n / LEAF)) * XPART) * sizeof(double);
 }
 
 // B (n x nrhs, column-major, device) := L^-T L^-1 B, 64 columns per pass through the images; `state`: TRSM_STATE_INTS ints of
@@ -811,10 +869,11 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
     static const int nchain_env = (int)tune("trsm_chain", 0);
     int nchain = nchain_env > 0 ? nchain_env : 4 * (MS_F + 2);
     if (nchain > 4 * T) nchain = 4 * T;
-    const int nstream = T < 256 - nchain ? T : 256 - nchain;
+    const int piece = piece_cap(T);
+    const size_t ntick = piece_tickets(T, piece);
+    const int nstream = ntick < (size_t)(256 - nchain) ? (int)ntick : 256 - nchain;      // one workgroup per CU: the grid is persistent
     const size_t img = (size_t)n * MS_YLD;
     double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img, *X = M + (size_t)T * MS_F * MFRAG;
-    const int piece = piece_cap();
     const size_t xbytes = piece_partials(T, piece) * XPART * sizeof(double);
     for (int c0 = 0; c0 < nrhs; c0 += MS_NC) {
         const int nc = nrhs - c0 < MS_NC ? nrhs - c0 : MS_NC;
@@ -825,7 +884,7 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
         if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
         TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, X, piece, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
         const bool dbg = TRSM_DBG && getenv("SGPR_TRSM_DBG") != nullptr;
-        if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * 16 * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * 16 * T); }
+        if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * DBGW * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * DBGW * T); }
         hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);
         SGPR_CHECK_LAUNCH();
         if (dbg) dbg_report(a, "forward", st);
