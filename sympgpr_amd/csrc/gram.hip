@@ -306,6 +306,9 @@ __global__ __launch_bounds__(GT) void predict_reg_kernel(int n0, const double *q
 // from the regular-GP guess (the reference runs MINPACK hybrd1, tol 1e-13, per point and step, each
 // residual an O(n^2) matmul with Kyinv); here alpha = Kyinv ztrain is cached, a residual is one
 // block-wide reduction over the training points, and all nm steps run without leaving the GPU.
+constexpr int MAP_TEAM_T = 256;     // threads of a team member
+constexpr int MAP_TEAM_MAX = 16;    // members of a team at most
+constexpr int MAP_STAGE = 5;        // rounds of TT training points a member keeps in LDS (7 doubles per point: 70 KB at 256 threads)
 struct MapArgs {
     int nm, ntest, n0, n0p, mode, maxiter;
     int S;                                // workgroups per orbit (the team): each sums its share of the training points
@@ -319,6 +322,8 @@ struct MapArgs {
     KConst kc, kcp;
 };
 
+// `sh`: 2 * (TT / 64) doubles that the call before did NOT use (the callers alternate between two: a wave that is still reading
+// the sums of call n cannot be overtaken by the writes of call n + 2, because call n + 1's barrier lies between)
 template <int TT>
 __device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
 {
@@ -326,7 +331,6 @@ __device__ __forceinline__ void block_sum2(double &a, double &b, double *sh)
         a += __shfl_down(a, o, 64);
         b += __shfl_down(b, o, 64);
     }
-    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
         sh[2 * (threadIdx.x >> 6)] = a;
         sh[2 * (threadIdx.x >> 6) + 1] = b;
@@ -363,8 +367,8 @@ __device__ __forceinline__ void granule_load2(const unsigned long long *p, uint4
 template <int FAM, int TT>
 __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
 {
-    __shared__ double sh[2 * (TT / 64)];
-    __shared__ double sp[2][8];
+    __shared__ double sh[2][2 * (TT / 64)];
+    __shared__ double sp[2][2][MAP_TEAM_MAX];           // [parity of the call]
     const int S = a.S, k = blockIdx.x / S, me = blockIdx.x - k * S;
     unsigned seq = 0;
     bool lost = false;                                  // a team member did not answer in time: the orbit is lost (NaN), a.err says why
@@ -372,9 +376,9 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
     // ONE pair of granules per member, collected by lanes 0 .. S - 1.  (Tried: every wave publishing its own part, 4 S and 16 S
     // granule pairs to collect -- no gain at 256 threads, 40 instead of 65 G pair evaluations per second at 1024.)
     auto team_sum2 = [&](double &x, double &y) {
-        block_sum2<TT>(x, y, sh);
-        if (S == 1) return;
         ++seq;
+        block_sum2<TT>(x, y, sh[seq & 1u]);
+        if (S == 1) return;
         if (threadIdx.x == 0) {
             unsigned long long *mine = a.tw + (((size_t)k * S + me) * 2 + (seq & 1u)) * 4;
             granule_store(mine, x, seq);
@@ -391,33 +395,73 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
                 if (u[2] == seq && v[2] == seq) break;
                 if ((++it & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { ok = false; break; }    // 2 s
             }
-            sp[0][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)u[1] << 32) | u[0])) : __builtin_nan("");
-            sp[1][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0])) : __builtin_nan("");
+            sp[seq & 1u][0][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)u[1] << 32) | u[0])) : __builtin_nan("");
+            sp[seq & 1u][1][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0])) : __builtin_nan("");
             if (!ok) atomicExch(a.err, 1);
         }
         __syncthreads();
         double sx = 0.0, sy = 0.0;
-        for (int m = 0; m < S; ++m) { sx += sp[0][m]; sy += sp[1][m]; }
-        x = sx; y = sy;
-        __syncthreads();
+        for (int m = 0; m < S; ++m) { sx += sp[seq & 1u][0][m]; sy += sp[seq & 1u][1][m]; }
+        x = sx; y = sy;                                 // (no barrier behind the reads: the next call writes the other halves)
     };
+    // This member's training points never change: they are staged in LDS once (a residual is a handful of points per thread, and
+    // their loads -- four per point, L2 latency each round -- were two thirds of its time at N0 = 16 384: 1.2 us per point and
+    // thread against ~0.4 of arithmetic).  Same points, same order per thread: same bits.  Slices that do not fit stay in memory.
+    __shared__ double st[7][MAP_STAGE * TT];            // x, y, alpha (two halves) of the symplectic GP; x, y, alpha of the guess
+    auto rounds_of = [&](int n) { return n > me * TT ? (n - me * TT + S * TT - 1) / (S * TT) : 0; };
+    const int nr = rounds_of(a.n0), nrp = rounds_of(a.n0p);
+    const bool staged = nr <= MAP_STAGE && nrp <= MAP_STAGE;
+    if (staged) {
+        for (int i = 0; i < nr; ++i) {
+            const int j = me * TT + (int)threadIdx.x + i * S * TT;
+            if (j < a.n0) {
+                st[0][i * TT + threadIdx.x] = a.xtr[j]; st[1][i * TT + threadIdx.x] = a.ytr[j];
+                st[2][i * TT + threadIdx.x] = a.alpha[j]; st[3][i * TT + threadIdx.x] = a.alpha[a.n0 + j];
+            }
+        }
+        for (int i = 0; i < nrp; ++i) {
+            const int j = me * TT + (int)threadIdx.x + i * S * TT;
+            if (j < a.n0p) {
+                st[4][i * TT + threadIdx.x] = a.xtrp[j]; st[5][i * TT + threadIdx.x] = a.ytrp[j]; st[6][i * TT + threadIdx.x] = a.alphap[j];
+            }
+        }
+        // (every thread reads back what it wrote itself: no barrier needed)
+    }
     unsigned ncalls = 0;                                // residual evaluations of this orbit (measurement aid)
     auto rows = [&](double q, double P, double &r1, double &r2) {   // Kstar(1,:).alpha, Kstar(2,:).alpha
         r1 = 0.0; r2 = 0.0;
         ++ncalls;
-        for (int j = me * TT + threadIdx.x; j < a.n0; j += S * TT) {
-            double kxx, kxy, kyy;
-            pair_eval<FAM, false>(a.xtr[j], a.ytr[j], q, P, a.kc, kxx, kxy, kyy);
-            const double a1 = a.alpha[j], a2 = a.alpha[a.n0 + j];
-            r1 += kxx * a1 + kxy * a2;
-            r2 += kxy * a1 + kyy * a2;
+        if (staged) {
+            for (int i = 0, j = me * TT + threadIdx.x; j < a.n0; ++i, j += S * TT) {
+                const int l = i * TT + threadIdx.x;
+                double kxx, kxy, kyy;
+                pair_eval<FAM, false>(st[0][l], st[1][l], q, P, a.kc, kxx, kxy, kyy);
+                const double a1 = st[2][l], a2 = st[3][l];
+                r1 += kxx * a1 + kxy * a2;
+                r2 += kxy * a1 + kyy * a2;
+            }
+        } else {
+            for (int j = me * TT + threadIdx.x; j < a.n0; j += S * TT) {
+                double kxx, kxy, kyy;
+                pair_eval<FAM, false>(a.xtr[j], a.ytr[j], q, P, a.kc, kxx, kxy, kyy);
+                const double a1 = a.alpha[j], a2 = a.alpha[a.n0 + j];
+                r1 += kxx * a1 + kxy * a2;
+                r2 += kxy * a1 + kyy * a2;
+            }
         }
         team_sum2(r1, r2);
     };
     auto guess = [&](double q, double p) {
         double r = 0.0, z = 0.0;
-        for (int j = me * TT + threadIdx.x; j < a.n0p; j += S * TT)
-            r += a.kcp.sig * kern_eval<FAM, false>(a.xtrp[j], a.ytrp[j], q, p, a.kcp) * a.alphap[j];
+        if (staged) {
+            for (int i = 0, j = me * TT + threadIdx.x; j < a.n0p; ++i, j += S * TT) {
+                const int l = i * TT + threadIdx.x;
+                r += a.kcp.sig * kern_eval<FAM, false>(st[4][l], st[5][l], q, p, a.kcp) * st[6][l];
+            }
+        } else {
+            for (int j = me * TT + threadIdx.x; j < a.n0p; j += S * TT)
+                r += a.kcp.sig * kern_eval<FAM, false>(a.xtrp[j], a.ytrp[j], q, p, a.kcp) * a.alphap[j];
+        }
         team_sum2(r, z);
         return r;
     };
@@ -637,14 +681,18 @@ int predict_rows(int family, int m, const double *q, const double *P, int n0, co
     });
 }
 
-// Workgroups per orbit: as many as fill the chip (256 CUs) with ntest orbits, at most 8, and no more than the training set can
-// feed with a round of 512 points each -- the drivers' own sizes (20 - 80 points) keep one workgroup per orbit.
-constexpr int MAP_TEAM_T = 512;     // threads of a team member (1024: 70 instead of 81 G pair evaluations per second; 256: 65)
+// Workgroups per orbit: TWO 256-thread members per CU (512 slots) shared out among the ntest orbits, at most 16 per orbit, and no
+// more than the training set can feed with a round of 256 points each -- the drivers' own sizes (20 - 80 points) keep one
+// workgroup per orbit.  Two members of DIFFERENT orbits per CU is the point: a residual is ~3.5 us of VALU work per CU and ~5 us
+// of reduction + exchange with the rest of the team, and with one 512-thread member per CU (the first form: 81 G pair
+// evaluations per second at N0 = 16 384, Ntest = 37) the CU idles through the exchange; with two the other orbit computes.
+// Every member of a team has to be resident at once (they wait for each other): 512 workgroups of 4 waves fit the chip at
+// <= 170 VGPRs (3 waves per SIMD; family A, the largest, has 136).
 int applymap_team(int ntest, int n0)
 {
-    int S = ntest > 0 ? 256 / ntest : 1;
-    S = std::min(S, (n0 + 511) / 512);
-    return std::max(1, std::min(S, 8));
+    int S = ntest > 0 ? 512 / ntest : 1;
+    S = std::min(S, (n0 + MAP_TEAM_T - 1) / MAP_TEAM_T);
+    return std::max(1, std::min(S, MAP_TEAM_MAX));
 }
 size_t applymap_team_ws(int ntest, int n0)
 {

@@ -467,7 +467,7 @@ def test_applymap_orbit_shared_by_several_workgroups(oracle):
     from sympgpr_amd.fit import SympFit
     rng = np.random.default_rng(21)
     Nt, Ntest, nm = 1500, 20, 4
-    assert L.load_probe_library().sgpr_probe_map_team(Ntest, Nt) == 3
+    assert L.load_probe_library().sgpr_probe_map_team(Ntest, Nt) == 6      # ceil(1500 / 256) members per orbit
     q, pn = rng.uniform(0, 2 * np.pi, Nt), rng.uniform(-1, 1, Nt)
     p_old = pn + 0.3 * np.sin(q); Q = q + 0.3 * pn               # a gentle symplectic map as training data
     ztrain = np.hstack((p_old - pn, Q - q))
