@@ -411,6 +411,15 @@ extern "C" int sgpr_probe_tune(const char *name, double value)
 }
 extern "C" unsigned sgpr_probe_map_calls(void) { return applymap_last_calls(); }
 extern "C" int sgpr_probe_map_team(int ntest, int n0) { return applymap_team(ntest, n0); }
+extern "C" int sgpr_probe_trsm_piece(int ticket, int cap, int out[4]) { if (ticket < 0 || cap < 1 || !out) return SGPR_E_ARG; trsm_piece_of(ticket, cap, out); return 0; }
+extern "C" int sgpr_probe_trsm_counts(int strips, int cap, unsigned long long out[2])
+{
+    if (strips < 0 || cap < 1 || !out) return SGPR_E_ARG;
+    size_t c[2];
+    trsm_piece_counts(strips, cap, c);
+    out[0] = c[0]; out[1] = c[1];
+    return 0;
+}
 
 // ---- co-residency census: where and when do the workgroups of two concurrent kernels run?
 // Kernel A (grid na, lds_a bytes of dynamic LDS, spins spin_a us) on one stream, kernel B (nb, lds_b, spin_b) on

@@ -834,6 +834,15 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
 
 }  // namespace
 
+// host view of the stream tickets (libsympgpr_probe.so, tests/test_boundary_cpu.py): ticket u of a solve whose pieces take at
+// most C tiles -> (strip, piece, pieces, slot of the strip's first partial sum); counts for T strips -> (tickets, partial sums)
+void trsm_piece_of(int u, int C, int out[4])
+{
+    const Piece p = piece_of(u, C);
+    out[0] = p.tk; out[1] = p.p; out[2] = p.np; out[3] = p.x0;
+}
+void trsm_piece_counts(int T, int C, size_t out[2]) { out[0] = piece_tickets(T, C); out[1] = piece_partials(T, C); }
+
 bool trsm_strips_ok(int n, const double *L, size_t ldl)
 {
     static const bool off = [] { const char *e = getenv("SGPR_TRSM"); return e && e[0] == 'r'; }();

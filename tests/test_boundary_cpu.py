@@ -240,3 +240,37 @@ def test_family_table_and_period_parameter():
         assert re.search(r"SGPR_FAM_%s\s*=\s*%d\b" % (name, val), hdr), name
     assert L.family_has_p("D") and not any(L.family_has_p(f) for f in "ABC")
     assert L.family_has_p("USER") in (False, True)
+
+
+@pytest.mark.parametrize("T,cap", [(5, 16), (22, 16), (128, 16), (133, 128), (134, 128), (300, 7), (768, 128), (1024, 64)])
+def test_block_solve_ticket_order(T, cap):
+    """The block solve deals its stream work out as tickets = pieces of strips (csrc/trsm.hip: piece_of; host logic, no GPU):
+    every (strip, piece) exactly once, strips ascending and the owner (last piece) of a strip behind its helpers -- so every wait
+    of a ticket is for a smaller one --, no piece longer than the cap, the partial-sum slots of the helpers dense and unique, and
+    the totals the host sizes the grid and the scratch with."""
+    import ctypes as C
+    from sympgpr_amd import _lib as L
+    probe = L.load_probe_library()
+    F = 5                                                    # TRSM_FOLD: tiles next to the diagonal are folded, not streamed
+    counts = (C.c_ulonglong * 2)()
+    L.check(probe.sgpr_probe_trsm_counts(T, cap, counts))
+    ntick, npart = int(counts[0]), int(counts[1])
+    out = (C.c_int * 4)()
+    seen, slots, last = set(), set(), (-1, -1)
+    for u in range(ntick):
+        L.check(probe.sgpr_probe_trsm_piece(u, cap, out))
+        tk, p, npc, x0 = (int(v) for v in out)
+        assert 0 <= tk < T and 0 <= p < npc
+        assert (tk, p) > last and (tk, p) not in seen         # ascending: helpers before their owner, strips in order
+        last = (tk, p)
+        seen.add((tk, p))
+        ns = max(tk - F, 0)
+        assert npc == max(1, -(-ns // cap))
+        q0, q1 = p * ns // npc, (p + 1) * ns // npc           # the piece's share of the strip's tiles (stream_task)
+        assert q1 - q0 <= cap
+        if p < npc - 1:
+            assert x0 + p not in slots
+            slots.add(x0 + p)
+    L.check(probe.sgpr_probe_trsm_piece(ntick, cap, out))
+    assert out[0] == T and out[1] == 0                        # the first ticket past the end belongs to strip T: the grid's exit
+    assert len(seen) == ntick and slots == set(range(npart))
