@@ -71,7 +71,9 @@ int sgpr_probe_queue_force_giveup(int on);
  * to the look-ahead driver, 0), q_kcap, q_leaf_us / q_pair_us / q_fixed_us / q_band0_us (planner's cost model), q_pollcap (2),
  * q_slack (CUs left empty, 0), q_nosync, q_debug.  Look-ahead driver: la_panel (3 = persistent panel kernel, 1 / 2 / 0 the
  * multi-launch panels), la_t0 / la_t1 / la_t2 (width thresholds).  GEMM: gemm_small_tile, gemm_small_mb.  Batched fits:
- * batch_two_min (512).  Block solves: trsm_chain (workgroups of the chain class, 0 = built-in). */
+ * batch_two_min (512), batch_below (workgroups for the strips below a panel's diagonal block, 0 = one per strip; read per call).
+ * Block solves: trsm_chain (workgroups of the chain class, 0 = built-in), trsm_piece (tiles per stream ticket, 0 = built-in: 16 up
+ * to 128 strips, 128 above; read per call). */
 int sgpr_probe_tune(const char *name, double value);
 /* the last sgpr_applymap_host of this process: K*-row evaluations (residuals of the implicit equation + q updates) summed over
  * its orbits, and the number of workgroups that share one orbit for ntest orbits on n0 training points */
