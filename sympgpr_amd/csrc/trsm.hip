@@ -28,9 +28,10 @@
 // and the hand-over S; P and S start as all-ones bit patterns.
 //
 // Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility):
-//   * chain <- chain, chain <- stream (S): the data is its own signal.  8-byte write-through (sc1) stores of values that are
-//     never the all-ones pattern (NaNs are canonicalised), consumers re-load their elements (sc1) until none is the pattern
-//     ("8-byte granules"; the form trsv.hip uses).  M_f is stored (sc1) and drained before the first element of S goes out.
+//   * chain <- chain, chain <- stream (S), piece <- piece (running partial sums): the data is its own signal.  8-byte
+//     write-through (sc1) stores of values that are never the all-ones pattern (NaNs are canonicalised), consumers re-load their
+//     elements (sc1) until none is the pattern ("8-byte granules"; the form trsv.hip uses).
+//   * chain <- stream (op(inv) and the folded tiles M_f): stored (sc1), drained, barrier, one relaxed store to the strip's flag.
 //   * stream <- chain (bulk reads of published segments by LDS-DMA): per quarter a progress counter, raised behind drain +
 //     workgroup barrier; the reader polls the four counters once (one lane), ONE agent-scope acquire, vmcnt(0), barrier.
 // Every stream task also starts with an acquire.  Forward progress: chain workgroups have the lowest block ids (dispatched
@@ -80,6 +81,7 @@ constexpr int B_ELEMS = MS_BK == 16 ? 1280 : 2560;
 constexpr int A_STAGES = MS_BK == 16 ? 7 : 3, B_STAGES = MS_BK == 16 ? 3 : 2;
 constexpr int A_W0 = 0, A_NW = 6, B_W0 = 6, B_NW = 2;   // waves 0..5 issue the copies of L, waves 6, 7 those of the segment
 constexpr int MFRAG = LEAF * LEAF;           // doubles of one folded tile M_f
+constexpr int MSLOTS = TRSM_FOLD + 1;        // fragment-ordered operands of a chain task per strip: op(inv), M_1 .. M_F
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
@@ -95,7 +97,8 @@ struct TrsmArgs {
     const double *Bin;     // image of the right-hand sides
     double *P;             // image of the solution, all-ones on entry
     double *S;             // image of the hand-over stream -> chain, all-ones on entry
-    double *M;             // T * MS_F * MFRAG doubles: the folded tiles, fragment order
+    double *M;             // T * MSLOTS * MFRAG doubles, fragment order: per strip op(inv) (slot 0) and the folded tiles M_1 .. M_F
+    int *mflag;            // per strip: set once the strip's slots are complete (zero on entry)
     double *X;             // partial sums of the strips that are streamed in several pieces, XPART doubles each, all-ones on entry
     int piece;             // most tiles one stream task takes (piece_of)
     int *state;            // [0] stream ticket, [1] chain ticket, [2] give-up flag
@@ -116,8 +119,8 @@ constexpr unsigned long long UNPUBLISHED = ~0ull;
 // A stream ticket = one PIECE of a strip.  Strip tk streams ns = tk - MS_F tiles; dealt whole, the last tickets are the longest
 // tasks of the launch (n = 98304: 7.7 ms each of 17) and the chip idles behind them for half of that on average.  So a strip
 // with more than C tiles goes out as np = ceil(ns / C) tickets over equal shares of its tiles, oldest segments first: the
-// first np - 1 (helpers) leave their 128 x 64 partial sums in X, the last one (the owner: the youngest segments, the fold and
-// the hand-over S) adds them in piece order.  Tickets stay in dependency order: a helper waits only for segments older than
+// first np - 1 (helpers) pass a running 128 x 64 partial sum along through X (piece p adds piece p - 1's), the last one (the owner:
+// the youngest segments, the fold and the hand-over S) takes the sum of all before it.  Tickets stay in dependency order: a helper waits only for segments older than
 // the owner's, the owner for its helpers (smaller tickets).
 struct Piece { int tk, p, np, x0; };         // strip, piece, pieces, slot of the strip's first partial sum in X
 constexpr size_t XPART = (size_t)LEAF * 64;
@@ -491,7 +494,7 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
     // ---- M_f = op(inv) op(tile_{tk-f}), f = 1 .. nfold, 64 columns per pass, stored in fragment order (write-through)
     for (int f = 1; f <= nfold; ++f) {
         const double *tl = tile_ptr(tk - f);
-        double *Mf = a.M + ((size_t)s * MS_F + (f - 1)) * MFRAG;
+        double *Mf = a.M + ((size_t)s * MSLOTS + f) * MFRAG;
         for (int pass = 0; pass < 2; ++pass) {
             zero_acc(acc);
             // A = op(inv): forward N image (rows contiguous), backward T image (the inverse acts transposed).
@@ -508,6 +511,20 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
 #pragma unroll
                     for (int r = 0; r < 4; ++r) store_sc1(Mf + frag_index(row_of(x, r), 64 * pass + col_of(y)), acc[x][y][r]);
         }
+    }
+    if (owner) {
+        // slot 0: op(inv_s) itself in fragment order (the chain multiplies S with it like any M_f), then the strip's flag: the
+        // chain task may start on its products with the segments that are already there long before S is -- every slot store
+        // drained, barrier, one relaxed store
+        double *M0 = a.M + (size_t)s * MSLOTS * MFRAG;
+#pragma unroll 4
+        for (int e = 0; e < LEAF * LEAF / MS_T; ++e) {
+            const int idx = tid + MS_T * e, i = idx & (LEAF - 1), k = idx >> 7;
+            store_sc1(M0 + frag_index(i, k), fwd ? inv_s[i + LEAF * k] : inv_s[k + LEAF * i]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((gi32 *)(a.mflag + s), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(1);
     // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q.  Both operands are linear streams: forward, tile (s, q + 1) follows
@@ -533,20 +550,13 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
         if (!stream_products<AT, false, true>(acc, q1 - q0, oa, ob, c, smem)) return false;
     }
     stamp(2);
-    // ---- a helper leaves its partial sum (value v of thread tid at [v][tid]: the owner's same thread takes it back) ...
-    if (!owner) {
-        double *xs = a.X + (size_t)(pc.x0 + pc.p) * XPART + tid;
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) publish(xs + (size_t)((x * 2 + y) * 4 + r) * MS_T, acc[x][y][r]);
-        return true;
-    }
-    // ... and the owner adds them in piece order (8-byte granules: re-loaded until none is the all-ones pattern)
-    for (int p = 0; p + 1 < pc.np; ++p) {
-        const double *xs = a.X + (size_t)(pc.x0 + p) * XPART + tid;
+    // ---- RUNNING partial sums: piece p adds what piece p - 1 left (the sum of pieces 0 .. p - 1; value v of thread tid at
+    // [v][tid], 8-byte granules re-loaded until none is the all-ones pattern) and, unless it is the owner, leaves the new sum for
+    // piece p + 1.  The owner therefore takes ONE partial sum on the way to S, however many pieces the strip has (gathering all
+    // of them itself cost 1 us each there, on the cycle that bounds chain-bound launches); a helper's wait is for a piece that
+    // covers older segments and started earlier.
+    if (pc.p > 0) {
+        const double *xs = a.X + (size_t)(pc.x0 + pc.p - 1) * XPART + tid;
         unsigned long long bits[16];
         unsigned long long t0 = 0;
         unsigned it = 0;
@@ -567,6 +577,16 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
             for (int y = 0; y < 2; ++y)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[x][y][r] += __longlong_as_double((long long)bits[(x * 2 + y) * 4 + r]);
+    }
+    if (!owner) {
+        double *xs = a.X + (size_t)(pc.x0 + pc.p) * XPART + tid;
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) publish(xs + (size_t)((x * 2 + y) * 4 + r) * MS_T, acc[x][y][r]);
+        return true;
     }
     // ---- S = -acc = B_s - sums -> the hand-over image.  Every M_f store of this workgroup has been drained by now (each wave waits
     // for vmcnt(0) in front of every barrier of the products above; explicitly once more here): S is the chain's signal.
@@ -665,58 +685,61 @@ __device__ __forceinline__ void chain_task(const TrsmArgs &a, int u, int tid, do
     const int T = a.T, tk = u >> 2, cq = u & 3;
     const int s = fwd ? tk : T - 1 - tk;
     const int nfold = tk < MS_F ? tk : MS_F;
-    const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
     auto stamp = [&](int i) { if (TRSM_DBG && a.dbg && tid == 0 && cq == 0) a.dbg[DBGW * tk + i] = __builtin_amdgcn_s_memrealtime(); };
     // two LDS images of a quarter segment, used in turn: product n + 2 writes the image product n read, and every wave has
     // passed the barrier of product n + 1 -- behind its reads of product n -- by then
     double *const qb0 = smem, *const qb1 = smem + LEAF * 16;
-    int nq = 0;
-    double af[32];
     bool ok = true;
-    // Z = op(inv_s) S: fragments op(inv)[16 w + l15][4 kk + l4]
-    const int i = 16 * wave + l15;
-#pragma unroll
-    for (int kk = 0; kk < 32; ++kk) {
-        const int k = 4 * kk + l4;
-        af[kk] = fwd ? inv_s[i + LEAF * k] : inv_s[k + LEAF * i];
+    // Y_s = op(inv_s) S - sum_{f = F..1} M_f Y_{s-+f} as nfold + 1 products, ordered by when their right-hand operands arrive:
+    //   M_F Y_{s-+F}, ..., M_2 Y_{s-+2}   (segments published two and more steps ago)
+    //   op(inv_s) S                       (S: the stream task's hand-over, F + 1 steps behind the chain)
+    //   M_1 Y_{s-+1}                      (the predecessor: the chain itself)
+    // -- with S first, as this began, every task sat waiting for S and THEN had all F + 1 products in front of it, on the cycle
+    // (stream tail + chain task, over F + 1 strips) that bounds the launch at chain-bound orders.
+    const int nops = nfold + 1, pos_inv = nfold > 1 ? nfold - 1 : 0;
+    auto slot_of = [&](int j) { return j < pos_inv ? nfold - j : (j == pos_inv ? 0 : 1); };
+    auto seg_of = [&](int j) {
+        const int f = slot_of(j);
+        if (f == 0) return (const double *)(a.S + (size_t)s * LEAF * MS_YLD + 16 * cq);
+        const int q = tk - f;                                  // the segment published q-th
+        return (const double *)(a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD + 16 * cq);
+    };
+    // the strip's slots are complete?  (set by the owner of the strip's stream work behind its fold; every wave looks itself)
+    {
+        unsigned long long t0 = 0;
+        unsigned it = 0;
+        while (__hip_atomic_load((gi32 *)(a.mflag + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            if (it == 0) t0 = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_sleep(8);
+            if ((++it & 63u) == 0 && (gave_up(a.state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) { ok = false; break; }
+        }
     }
-    // the fragments of M_f, f = nfold .. 1, one product ahead (plain 16-byte loads: these lines were stored write-through and
-    // drained before S went out, and this CU has never read them)
+    // fragments of the operands, one product ahead (plain 16-byte loads: these lines were stored write-through and drained
+    // before the flag went out, and this CU has never read them)
+    double af[32];
     double2_t an[16];
     auto load_m = [&](int f) {
-        const double *Mf = a.M + ((size_t)((TRSM_DBG && a.fake_b == 2) ? 0 : s) * MS_F + (f - 1)) * MFRAG + ((size_t)(wave * 16) * 64 + lane) * 2;   // (experiment 2: every strip reads strip 0's folded tiles -- cache-hot, wrong results)
+        const double *Mf = a.M + ((size_t)((TRSM_DBG && a.fake_b == 2) ? 0 : s) * MSLOTS + f) * MFRAG + ((size_t)(wave * 16) * 64 + lane) * 2;   // (experiment 2: every strip reads strip 0's slots -- cache-hot, wrong results)
 #pragma unroll
         for (int p = 0; p < 16; ++p) an[p] = *reinterpret_cast<const double2_t *>(Mf + (size_t)p * 128);
     };
-    auto seg_of = [&](int f) {                                // the segment M_f multiplies: the one published (tk - f)-th
-        const int q = tk - f;
-        return a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD + 16 * cq;
-    };
-    const double *sseg = a.S + (size_t)s * LEAF * MS_YLD + 16 * cq;
     QuarterRows rows, next;
     double4_t z = double4_t{0.0, 0.0, 0.0, 0.0};
-    quarter_ask(rows, sseg, wave, l15, l4);
-    ok &= quarter_have(rows, sseg, a.state, wave, l15, l4);
-    if (nfold > 0) load_m(nfold);        // (behind the wait for S: M_f is complete once S is there)
-    quarter_multiply(z, af, rows, (nq++ & 1) ? qb1 : qb0, wave, l15, l4, [&]() { if (nfold > 0) quarter_ask(next, seg_of(nfold), wave, l15, l4); });
-    stamp(4);
-    for (int f = nfold; f >= 1; --f) {
-        if (f == 2) stamp(16);
+    if (ok) load_m(slot_of(0));
+    quarter_ask(next, seg_of(0), wave, l15, l4);
+    for (int j = 0; j < nops; ++j) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) { af[2 * p] = an[p].x; af[2 * p + 1] = an[p].y; }
-        if (TRSM_DBG && a.dbg && f == 2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); stamp(17); }    // (the four row loads of `next` are younger)
-        if (f > 1) load_m(f - 1);
-        if (f == 2) stamp(18);
-        ok &= quarter_have(next, seg_of(f), a.state, wave, l15, l4);
-        if (f == 2) stamp(19);
+        if (j + 1 < nops) load_m(slot_of(j + 1));
+        ok &= quarter_have(next, seg_of(j), a.state, wave, l15, l4);
         rows = next;
         double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
-        quarter_multiply(acc, af, rows, (nq++ & 1) ? qb1 : qb0, wave, l15, l4, [&]() { if (f > 1) quarter_ask(next, seg_of(f - 1), wave, l15, l4); },
-                         (TRSM_DBG && a.dbg && tid == 0 && cq == 0 && f <= 2) ? a.dbg + DBGW * tk + (f == 1 ? 13 : 21) : nullptr);
-        if (f == 1) stamp(5);
-        z -= acc;
-        if (f == 2) stamp(20);
+        quarter_multiply(acc, af, rows, (j & 1) ? qb1 : qb0, wave, l15, l4, [&]() { if (j + 1 < nops) quarter_ask(next, seg_of(j + 1), wave, l15, l4); },
+                         (TRSM_DBG && a.dbg && tid == 0 && cq == 0 && j == nops - 1) ? a.dbg + DBGW * tk + 13 : nullptr);
+        if (j == pos_inv) { z += acc; stamp(4); }
+        else              z -= acc;
     }
+    stamp(5);
     // publish: element (row 16 w + 4 r + l4, column 16 cq + l15)
     double *ps = a.P + (size_t)s * LEAF * MS_YLD + (size_t)(16 * wave + l4) * MS_YLD + 16 * cq + l15;
 #pragma unroll
@@ -799,7 +822,7 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
     (void)hipMemset(a.dbg, 0, h.size() * 8);
     auto us = [&](int t, int i, int t2, int j) { return ((double)h[DBGW * t + i] - (double)h[DBGW * t2 + j]) * 0.01; };
     auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
-    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last, mhz, c0, c1, c2, p0, p1, p2, p3, p4, p5, p6;
+    std::vector<double> step, prep, tile, freetile, spub, slead, zdone, hop, last, mhz, c0, c1, c2;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int t = 0; t < T; ++t)
         for (int i = 0; i < 8; ++i)
@@ -820,16 +843,13 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
         c0.push_back(us(t, 13, t - 1, 6));                   // ... -> wave 0 has its rows of the predecessor's segment
         c1.push_back(us(t, 14, t, 13));                      // ... -> every wave has, LDS image complete
         c2.push_back(us(t, 15, t, 14));
-        // the product before the last one, phase by phase (wave 0 of quarter 0)
-        p0.push_back(us(t, 17, t, 16)); p1.push_back(us(t, 18, t, 17)); p2.push_back(us(t, 19, t, 18)); p3.push_back(us(t, 21, t, 19));
-        p4.push_back(us(t, 22, t, 21)); p5.push_back(us(t, 23, t, 22)); p6.push_back(us(t, 20, t, 23));                      // ... -> fragments read, 32 MFMAs done
+                      // ... -> fragments read, 32 MFMAs done
         last.push_back(us(t, 6, t, 5));                      // publish
     }
     fprintf(stderr, "trsm %s T=%d: step %.2f us | fold %d tiles %.1f us | streamed tile %.2f us each, %.2f before the first wait (%d strips waited) | S out %.1f | "
-            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us | shader clock %.0f MHz | last product: published -> wave 0 has it %.2f, -> all waves %.2f, -> MFMAs done %.2f | product 2 by phase: M_2 landed %.2f, M_1 asked for %.2f, rows there %.2f, into the product %.2f, "
-            "LDS + barrier %.2f, reads + MFMAs %.2f, out %.2f\n",
+            "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us | shader clock %.0f MHz | last product: published -> wave 0 has it %.2f, -> all waves %.2f, -> MFMAs done %.2f\n",
             what, T, med(step), MS_F, med(prep), med(tile), med(freetile), nwaited, med(spub), med(slead), med(zdone), med(hop), med(last),
-            (double)(tmax - tmin) * 0.01, med(mhz), med(c0), med(c1), med(c2), med(p0), med(p1), med(p2), med(p3), med(p4), med(p5), med(p6));
+            (double)(tmax - tmin) * 0.01, med(mhz), med(c0), med(c1), med(c2));
 }
 
 }  // namespace
@@ -851,19 +871,21 @@ bool trsm_strips_ok(int n, const double *L, size_t ldl)
 }
 
 // most tiles of L one stream task takes (piece_of); tunable "trsm_piece" (sgpr_probe_tune)
-// Default: 128 (n = 65 536 ... 98 304: 64 ... 256 within 3 %); 16 up to 128 strips, where every stream task sits at the chain's
-// frontier for its whole life and shorter pieces put the idle half of the chip to work (n = 8192 / 16 384: 1.32 -> 1.27 /
-// 2.46 -> 2.39 ms; at 256 strips 16 is slower than 128: 5.2 against 5.0 ms).
+// Default: 128 (n = 65 536 ... 98 304: 64 ... 256 within 3 %); T / 16, at least 4, up to 256 strips, where every stream task sits at
+// the chain's frontier for its whole life: what a task lags per frontier tile adds up over its tiles, on the cycle that bounds
+// the launch, and shorter pieces also put the idle part of the chip to work (measured with the running sums, ms at n = 8192 /
+// 16 384 / 32 768: 4 tiles 1.01 / 2.11 / 7.5, 8 tiles 1.10 / 1.95 / 5.3, 16 tiles 1.18 / 2.13 / 4.68, 32 tiles 1.26 / 2.29 / 4.66).
 static int piece_cap(int T)
 {
     const int v = (int)tune("trsm_piece", 0);
-    return v <= 0 ? (T <= 128 ? 16 : 128) : (v < 4 ? 4 : v);
+    return v <= 0 ? (T <= 256 ? (T / 16 < 4 ? 4 : T / 16) : 128) : (v < 4 ? 4 : v);
 }
 
 // bytes of scratch: three images, the folded tiles and the partial sums of the strips streamed in pieces
 size_t trsm_strips_scratch(int n)
 {
-    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MS_F * MFRAG + piece_partials(n / LEAF, piece_cap(n / LEAF)) * XPART) * sizeof(double);
+    return ((size_t)3 * n * MS_YLD + (size_t)(n / LEAF) * MSLOTS * MFRAG + piece_partials(n / LEAF, piece_cap(n / LEAF)) * XPART) * sizeof(double) +
+           (size_t)2 * (n / LEAF + 1) * sizeof(int);
 }
 
 // B (n x nrhs, column-major, device) := L^-T L^-1 B, 64 columns per pass through the images; `state`: TRSM_STATE_INTS ints of
@@ -882,8 +904,9 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
     const size_t ntick = piece_tickets(T, piece);
     const int nstream = ntick < (size_t)(256 - nchain) ? (int)ntick : 256 - nchain;      // one workgroup per CU: the grid is persistent
     const size_t img = (size_t)n * MS_YLD;
-    double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img, *X = M + (size_t)T * MS_F * MFRAG;
+    double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img, *X = M + (size_t)T * MSLOTS * MFRAG;
     const size_t xbytes = piece_partials(T, piece) * XPART * sizeof(double);
+    int *mflag = reinterpret_cast<int *>(X + piece_partials(T, piece) * XPART);     // T + 1 ints per triangular solve
     for (int c0 = 0; c0 < nrhs; c0 += MS_NC) {
         const int nc = nrhs - c0 < MS_NC ? nrhs - c0 : MS_NC;
         hipLaunchKernelGGL(pack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, B + (size_t)c0 * ldb, ldb, I0);
@@ -891,7 +914,8 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
         SGPR_HIP(hipMemsetAsync(state, 0, TRSM_STATE_INTS * sizeof(int), st));
         SGPR_HIP(hipMemsetAsync(I1, 0xFF, 2 * img * sizeof(double), st));       // P and S of the forward solve
         if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
-        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, X, piece, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
+        SGPR_HIP(hipMemsetAsync(mflag, 0, (size_t)2 * (T + 1) * sizeof(int), st));
+        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, mflag, X, piece, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
         const bool dbg = TRSM_DBG && getenv("SGPR_TRSM_DBG") != nullptr;
         if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * DBGW * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * DBGW * T); }
         hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);
@@ -902,7 +926,7 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
         SGPR_HIP(hipMemsetAsync(S, 0xFF, img * sizeof(double), st));
         if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
         a.Bin = I1; a.P = I0;
-        a.state = state + 4; a.ready = state + 12;
+        a.state = state + 4; a.ready = state + 12; a.mflag = mflag + T + 1;
         hipLaunchKernelGGL(trsm_strips_kernel<false>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);
         SGPR_CHECK_LAUNCH();
         if (dbg) { dbg_report(a, "backward", st); (void)hipFree(a.dbg); }
