@@ -80,9 +80,10 @@ int sgpr_probe_tune(const char *name, double value);
 unsigned sgpr_probe_map_calls(void);
 int sgpr_probe_map_team(int ntest, int n0);
 
-/* the block solve's stream tickets as the host computes them (csrc/trsm.hip: piece_of): ticket -> {strip, piece, pieces of the
- * strip, slot of the strip's first partial sum} for pieces of at most `cap` tiles; and for `strips` strips {tickets, partial sums} */
-int sgpr_probe_trsm_piece(int ticket, int cap, int out[4]);
+/* the block solve's stream tickets as the host computes them (csrc/trsm.hip: piece_of): ticket of a solve with `strips` strips ->
+ * {strip, piece, pieces of the strip, slot of the strip's first partial sum, 0 or the tile f whose fold the ticket is} for pieces
+ * of at most `cap` tiles (strip = strips: past the end); and for `strips` strips {tickets, partial sums} */
+int sgpr_probe_trsm_piece(int ticket, int cap, int strips, int out[5]);
 int sgpr_probe_trsm_counts(int strips, int cap, unsigned long long out[2]);
 
 /* co-residency census of two concurrent kernels (A: na workgroups of threads_a threads with lds_a bytes of LDS spinning

@@ -134,7 +134,7 @@ PROBE_SIGNATURES = {
     "sgpr_probe_tune": (C.c_int, [C.c_char_p, C.c_double]),
     "sgpr_probe_map_calls": (C.c_uint, []),
     "sgpr_probe_map_team": (C.c_int, [C.c_int, C.c_int]),
-    "sgpr_probe_trsm_piece": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "sgpr_probe_trsm_piece": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "sgpr_probe_trsm_counts": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
     "sgpr_probe_queue_trace_clear": (C.c_int, []),
     "sgpr_probe_census": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int,

@@ -146,7 +146,7 @@ constexpr int TRSM_YLD = 80;                                      // row stride 
 constexpr int TRSM_FOLD = 5;                                      // tiles next to the diagonal folded into the leaf inverse
 constexpr int TRSM_STATE_INTS = 16;                               // hand-off words of one forward + backward pair
 bool trsm_strips_ok(int n, const double *L, size_t ldl);
-void trsm_piece_of(int u, int C, int out[4]);                      // the stream tickets as the host sees them (tests)
+void trsm_piece_of(int u, int C, int T, int out[5]);                      // the stream tickets as the host sees them (tests)
 void trsm_piece_counts(int T, int C, size_t out[2]);
 size_t trsm_strips_scratch(int n);                                // bytes
 int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *B, size_t ldb, int nrhs, int *state /* TRSM_STATE_INTS ints */,

@@ -411,7 +411,7 @@ extern "C" int sgpr_probe_tune(const char *name, double value)
 }
 extern "C" unsigned sgpr_probe_map_calls(void) { return applymap_last_calls(); }
 extern "C" int sgpr_probe_map_team(int ntest, int n0) { return applymap_team(ntest, n0); }
-extern "C" int sgpr_probe_trsm_piece(int ticket, int cap, int out[4]) { if (ticket < 0 || cap < 1 || !out) return SGPR_E_ARG; trsm_piece_of(ticket, cap, out); return 0; }
+extern "C" int sgpr_probe_trsm_piece(int ticket, int cap, int strips, int out[5]) { if (ticket < 0 || cap < 1 || strips < 0 || !out) return SGPR_E_ARG; trsm_piece_of(ticket, cap, strips, out); return 0; }
 extern "C" int sgpr_probe_trsm_counts(int strips, int cap, unsigned long long out[2])
 {
     if (strips < 0 || cap < 1 || !out) return SGPR_E_ARG;

@@ -98,7 +98,7 @@ struct TrsmArgs {
     double *P;             // image of the solution, all-ones on entry
     double *S;             // image of the hand-over stream -> chain, all-ones on entry
     double *M;             // T * MSLOTS * MFRAG doubles, fragment order: per strip op(inv) (slot 0) and the folded tiles M_1 .. M_F
-    int *mflag;            // per strip: set once the strip's slots are complete (zero on entry)
+    int *mflag;            // per strip: complete slots (zero on entry)
     double *X;             // partial sums of the strips that are streamed in several pieces, XPART doubles each, all-ones on entry
     int piece;             // most tiles one stream task takes (piece_of)
     int *state;            // [0] stream ticket, [1] chain ticket, [2] give-up flag
@@ -116,39 +116,50 @@ constexpr bool TRSM_DBG = false;   // per-strip time stamps (experiments: make E
 constexpr int DBGW = 32;                      // debug builds: stamp words per strip
 constexpr unsigned long long UNPUBLISHED = ~0ull;
 
-// A stream ticket = one PIECE of a strip.  Strip tk streams ns = tk - MS_F tiles; dealt whole, the last tickets are the longest
-// tasks of the launch (n = 98304: 7.7 ms each of 17) and the chip idles behind them for half of that on average.  So a strip
-// with more than C tiles goes out as np = ceil(ns / C) tickets over equal shares of its tiles, oldest segments first: the
-// first np - 1 (helpers) pass a running 128 x 64 partial sum along through X (piece p adds piece p - 1's), the last one (the owner:
-// the youngest segments, the fold and the hand-over S) takes the sum of all before it.  Tickets stay in dependency order: a helper waits only for segments older than
-// the owner's, the owner for its helpers (smaller tickets).
-struct Piece { int tk, p, np, x0; };         // strip, piece, pieces, slot of the strip's first partial sum in X
+// A stream ticket = one PIECE of a strip's streamed tiles, or the FOLD of one of its tiles.  Strip tk streams ns = tk - MS_F
+// tiles; dealt whole, the last tickets are the longest tasks of the launch (n = 98304: 7.7 ms each of 17) and the chip idles
+// behind them for half of that on average.  So a strip with more than C tiles goes out as np = ceil(ns / C) tickets over equal
+// shares of its tiles, oldest segments first: the first np - 1 (helpers) pass a running 128 x 64 partial sum along through X
+// (piece p adds piece p - 1's), the last one (the owner: the youngest segments, op(inv) for the chain and the hand-over S) takes
+// the sum of all before it.  The folds M_f = op(inv) op(tile), f = 1 .. min(tk, F), are tickets of their own between the helpers
+// and the owner: five of them in a row were 144 us at the head of every launch -- a third of a solve at n = 4096 -- during which
+// the rest of the chip had nothing to do.  Tickets stay in dependency order: a helper waits only for segments older than the
+// owner's, a fold for nothing, the owner for its helpers (smaller tickets).
+struct Piece { int tk, p, np, x0, fold; };   // strip, piece, pieces, slot of the strip's first partial sum in X; fold: 0 or f
 constexpr size_t XPART = (size_t)LEAF * 64;
-__host__ __device__ inline Piece piece_of(int u, int C)
+// helper pieces (= partial sums) of the strips before tk: sum over ns = 1 .. tk - F - 1 of floor((ns - 1) / C), in closed form
+__host__ __device__ inline long pieces_before(int tk, int C)
 {
-    const int g0 = TRSM_FOLD + C + 1;        // strips 0 .. F + C: one piece
-    if (u < g0) return Piece{u, 0, 1, 0};
-    // group m >= 1: the C strips with m C < ns <= (m + 1) C, m + 1 tickets each
-    u -= g0;
-    int m = 1, x = 0;
-    while (u >= C * (m + 1)) { u -= C * (m + 1); x += C * m; ++m; }
-    const int j = u / (m + 1);
-    return Piece{g0 + (m - 1) * C + j, u % (m + 1), m + 1, x + j * m};
+    const long N = (long)tk - TRSM_FOLD - 1;
+    if (N <= 0) return 0;
+    const long a = N / C, b = N % C;
+    return (long)C * a * (a - 1) / 2 + a * b;
 }
-// stream tickets of a solve with T strips (host: sizes the grid)
-inline size_t piece_tickets(int T, int C)
+// tickets of the strips before tk: one owner each, the helper pieces, min(j, F) folds
+__host__ __device__ inline long tickets_before(int tk, int C)
 {
-    size_t x = 0;
-    for (int tk = 0; tk < T; ++tk) x += tk <= TRSM_FOLD + C ? 1 : (size_t)((tk - TRSM_FOLD + C - 1) / C);
-    return x;
+    const long folds = tk <= TRSM_FOLD ? (long)tk * (tk - 1) / 2 : (long)TRSM_FOLD * (TRSM_FOLD - 1) / 2 + (long)TRSM_FOLD * (tk - TRSM_FOLD);
+    return tk + pieces_before(tk, C) + folds;
 }
-// partial sums of a solve with T strips (host: sizes the scratch)
-inline size_t piece_partials(int T, int C)
+// ticket u of a solve with T strips (tk = T: past the end)
+__host__ __device__ inline Piece piece_of(int u, int C, int T)
 {
-    size_t x = 0;
-    for (int tk = TRSM_FOLD + C + 1; tk < T; ++tk) x += (size_t)((tk - TRSM_FOLD + C - 1) / C - 1);
-    return x;
+    int lo = 0, hi = T;                       // the largest tk with tickets_before(tk) <= u
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tickets_before(mid, C) <= u) lo = mid; else hi = mid - 1;
+    }
+    const int tk = lo;
+    if (tk >= T) return Piece{T, 0, 1, 0, 0};
+    const int v = u - (int)tickets_before(tk, C), ns = tk > TRSM_FOLD ? tk - TRSM_FOLD : 0, np = ns > C ? (ns + C - 1) / C : 1;
+    const int nfold = tk < TRSM_FOLD ? tk : TRSM_FOLD, x0 = (int)pieces_before(tk, C);
+    if (v < np - 1) return Piece{tk, v, np, x0, 0};
+    if (v < np - 1 + nfold) return Piece{tk, 0, np, x0, v - (np - 1) + 1};
+    return Piece{tk, np - 1, np, x0, 0};
 }
+// stream tickets / partial sums of a solve with T strips (host: sizes the grid and the scratch)
+inline size_t piece_tickets(int T, int C) { return (size_t)tickets_before(T, C); }
+inline size_t piece_partials(int T, int C) { return (size_t)pieces_before(T, C); }
 constexpr unsigned long long WAIT_LIMIT_TICKS = 500000000ull;   // 5 s of the 100 MHz real-time counter
 
 __device__ __forceinline__ void store_sc1(double *p, double v)
@@ -462,7 +473,7 @@ template <bool fwd>
 __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, Ctl &c, double *smem)
 {
     const int tk = pc.tk;
-    const bool owner = pc.p == pc.np - 1;
+    const bool owner = !pc.fold && pc.p == pc.np - 1;
     const int tid = c.tid, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 3, wn = wave >> 2, l15 = lane & 15, l4 = lane >> 4;
     const int T = a.T;
@@ -478,7 +489,7 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
     };
     auto seg_ptr = [&](int q) { return a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD; };
     const double *inv_s = a.inv + (size_t)s * LEAF * LEAF;
-    const int nfold = !owner ? 0 : (tk < MS_F ? tk : MS_F), ns = tk - (tk < MS_F ? tk : MS_F);
+    const int ns = tk - (tk < MS_F ? tk : MS_F);
     const int q0 = (int)((long)pc.p * ns / pc.np), q1 = (int)((long)(pc.p + 1) * ns / pc.np);   // this piece's dependencies
     auto stamp = [&](int i) {
         if (TRSM_DBG && a.dbg && tid == 0 && owner) {
@@ -491,8 +502,10 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
     c.dbg_wait = (TRSM_DBG && a.dbg && owner) ? a.dbg + DBGW * tk + 8 : nullptr;
     c.qbase = q0;
     double4_t acc[2][2];
-    // ---- M_f = op(inv) op(tile_{tk-f}), f = 1 .. nfold, 64 columns per pass, stored in fragment order (write-through)
-    for (int f = 1; f <= nfold; ++f) {
+    // ---- a fold ticket: M_f = op(inv) op(tile_{tk-f}), 64 columns per pass, stored in fragment order (write-through); then the
+    // strip's count of complete slots goes up by one (every store drained, barrier, one relaxed add)
+    if (pc.fold) {
+        const int f = pc.fold;
         const double *tl = tile_ptr(tk - f);
         double *Mf = a.M + ((size_t)s * MSLOTS + f) * MFRAG;
         for (int pass = 0; pass < 2; ++pass) {
@@ -511,11 +524,15 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
 #pragma unroll
                     for (int r = 0; r < 4; ++r) store_sc1(Mf + frag_index(row_of(x, r), 64 * pass + col_of(y)), acc[x][y][r]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) (void)__hip_atomic_fetch_add((gi32 *)(a.mflag + s), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
     }
     if (owner) {
-        // slot 0: op(inv_s) itself in fragment order (the chain multiplies S with it like any M_f), then the strip's flag: the
-        // chain task may start on its products with the segments that are already there long before S is -- every slot store
-        // drained, barrier, one relaxed store
+        // slot 0: op(inv_s) itself in fragment order (the chain multiplies S with it like any M_f), counted like a fold: the chain
+        // task starts on its products, with the segments that are already there, once the strip's min(tk, F) + 1 slots are complete
+        // -- long before S is
         double *M0 = a.M + (size_t)s * MSLOTS * MFRAG;
 #pragma unroll 4
         for (int e = 0; e < LEAF * LEAF / MS_T; ++e) {
@@ -524,7 +541,7 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_store((gi32 *)(a.mflag + s), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) (void)__hip_atomic_fetch_add((gi32 *)(a.mflag + s), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp(1);
     // ---- streamed part: acc = sum_{q < ns} op(tile_q) Y_q.  Both operands are linear streams: forward, tile (s, q + 1) follows
@@ -704,11 +721,11 @@ __device__ __forceinline__ void chain_task(const TrsmArgs &a, int u, int tid, do
         const int q = tk - f;                                  // the segment published q-th
         return (const double *)(a.P + (size_t)(fwd ? q : T - 1 - q) * LEAF * MS_YLD + 16 * cq);
     };
-    // the strip's slots are complete?  (set by the owner of the strip's stream work behind its fold; every wave looks itself)
+    // the strip's slots are complete?  (counted up by the strip's fold tickets and its owner; every wave looks itself)
     {
         unsigned long long t0 = 0;
         unsigned it = 0;
-        while (__hip_atomic_load((gi32 *)(a.mflag + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        while (__hip_atomic_load((gi32 *)(a.mflag + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nfold + 1) {
             if (it == 0) t0 = __builtin_amdgcn_s_memrealtime();
             __builtin_amdgcn_s_sleep(8);
             if ((++it & 63u) == 0 && (gave_up(a.state) || __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS)) { ok = false; break; }
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
         if (tid == 0) {
             const int u = atomicAdd(a.state + (chain ? 1 : 0), 1);
             sh[2] = u;
-            if (!chain) { const Piece pc = piece_of(u, a.piece); sh[2] = pc.tk; sh[4] = pc.p; sh[5] = pc.np; sh[6] = pc.x0; }
+            if (!chain) { const Piece pc = piece_of(u, a.piece, a.T); sh[2] = pc.tk; sh[4] = pc.p; sh[5] = pc.np; sh[6] = pc.x0; sh[7] = pc.fold; }
             // what is published by now may be read without polling; the acquire also drops every line this CU's L1 holds of
             // rows that have been published since it read them
             int v = 0x7fffffff;
@@ -778,7 +795,7 @@ __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
         __syncthreads();
         const int tk = sh[2];
         c.known = sh[3];
-        const Piece pc{tk, sh[4], sh[5], sh[6]};
+        const Piece pc{tk, sh[4], sh[5], sh[6], sh[7]};
         __syncthreads();
         if (tk >= ntasks || c.known < 0) return;
         if (chain) {
@@ -846,7 +863,7 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
                       // ... -> fragments read, 32 MFMAs done
         last.push_back(us(t, 6, t, 5));                      // publish
     }
-    fprintf(stderr, "trsm %s T=%d: step %.2f us | fold %d tiles %.1f us | streamed tile %.2f us each, %.2f before the first wait (%d strips waited) | S out %.1f | "
+    fprintf(stderr, "trsm %s T=%d: step %.2f us | (F = %d) owner: slot 0 %.1f us | streamed tile %.2f us each, %.2f before the first wait (%d strips waited) | S out %.1f | "
             "S handed over %.1f us, Z formed %.1f us before the predecessor published | pred. published -> last product done %.2f | publish %.2f | whole launch %.1f us | shader clock %.0f MHz | last product: published -> wave 0 has it %.2f, -> all waves %.2f, -> MFMAs done %.2f\n",
             what, T, med(step), MS_F, med(prep), med(tile), med(freetile), nwaited, med(spub), med(slead), med(zdone), med(hop), med(last),
             (double)(tmax - tmin) * 0.01, med(mhz), med(c0), med(c1), med(c2));
@@ -855,11 +872,11 @@ static void dbg_report(const TrsmArgs &a, const char *what, hipStream_t st)
 }  // namespace
 
 // host view of the stream tickets (libsympgpr_probe.so, tests/test_boundary_cpu.py): ticket u of a solve whose pieces take at
-// most C tiles -> (strip, piece, pieces, slot of the strip's first partial sum); counts for T strips -> (tickets, partial sums)
-void trsm_piece_of(int u, int C, int out[4])
+// most C tiles -> (strip, piece, pieces, slot of the strip's first partial sum, fold or 0); counts for T strips -> (tickets, partial sums)
+void trsm_piece_of(int u, int C, int T, int out[5])
 {
-    const Piece p = piece_of(u, C);
-    out[0] = p.tk; out[1] = p.p; out[2] = p.np; out[3] = p.x0;
+    const Piece p = piece_of(u, C, T);
+    out[0] = p.tk; out[1] = p.p; out[2] = p.np; out[3] = p.x0; out[4] = p.fold;
 }
 void trsm_piece_counts(int T, int C, size_t out[2]) { out[0] = piece_tickets(T, C); out[1] = piece_partials(T, C); }
 

@@ -242,12 +242,12 @@ def test_family_table_and_period_parameter():
     assert L.family_has_p("USER") in (False, True)
 
 
-@pytest.mark.parametrize("T,cap", [(5, 16), (22, 16), (128, 16), (133, 128), (134, 128), (300, 7), (768, 128), (1024, 64)])
+@pytest.mark.parametrize("T,cap", [(1, 16), (5, 16), (22, 4), (128, 8), (133, 128), (134, 128), (300, 7), (768, 128), (1024, 64)])
 def test_block_solve_ticket_order(T, cap):
-    """The block solve deals its stream work out as tickets = pieces of strips (csrc/trsm.hip: piece_of; host logic, no GPU):
-    every (strip, piece) exactly once, strips ascending and the owner (last piece) of a strip behind its helpers -- so every wait
-    of a ticket is for a smaller one --, no piece longer than the cap, the partial-sum slots of the helpers dense and unique, and
-    the totals the host sizes the grid and the scratch with."""
+    """The block solve deals its stream work out as tickets (csrc/trsm.hip: piece_of; host logic, no GPU): per strip the helper
+    pieces of its streamed tiles, then the folds of its min(strip, F) tiles next to the diagonal, then the owner (the last piece)
+    -- strips ascending, so every wait of a ticket is for a smaller one --, no piece longer than the cap, the partial-sum slots
+    of the helpers dense and unique, and the totals the host sizes the grid and the scratch with."""
     import ctypes as C
     from sympgpr_amd import _lib as L
     probe = L.load_probe_library()
@@ -255,22 +255,26 @@ def test_block_solve_ticket_order(T, cap):
     counts = (C.c_ulonglong * 2)()
     L.check(probe.sgpr_probe_trsm_counts(T, cap, counts))
     ntick, npart = int(counts[0]), int(counts[1])
-    out = (C.c_int * 4)()
-    seen, slots, last = set(), set(), (-1, -1)
-    for u in range(ntick):
-        L.check(probe.sgpr_probe_trsm_piece(u, cap, out))
-        tk, p, npc, x0 = (int(v) for v in out)
-        assert 0 <= tk < T and 0 <= p < npc
-        assert (tk, p) > last and (tk, p) not in seen         # ascending: helpers before their owner, strips in order
-        last = (tk, p)
-        seen.add((tk, p))
+    out = (C.c_int * 5)()
+    expect, slots = [], set()
+    for tk in range(T):
+        ns = max(tk - F, 0)
+        npc = max(1, -(-ns // cap))
+        expect += [(tk, p, 0) for p in range(npc - 1)] + [(tk, 0, f) for f in range(1, min(tk, F) + 1)] + [(tk, npc - 1, 0)]
+    assert ntick == len(expect)
+    for u, (tk, p, f) in enumerate(expect):
+        L.check(probe.sgpr_probe_trsm_piece(u, cap, T, out))
+        got_tk, got_p, npc, x0, fold = (int(v) for v in out)
+        assert (got_tk, got_p, fold) == (tk, p, f), (u, tuple(out))
         ns = max(tk - F, 0)
         assert npc == max(1, -(-ns // cap))
-        q0, q1 = p * ns // npc, (p + 1) * ns // npc           # the piece's share of the strip's tiles (stream_task)
-        assert q1 - q0 <= cap
-        if p < npc - 1:
-            assert x0 + p not in slots
-            slots.add(x0 + p)
-    L.check(probe.sgpr_probe_trsm_piece(ntick, cap, out))
-    assert out[0] == T and out[1] == 0                        # the first ticket past the end belongs to strip T: the grid's exit
-    assert len(seen) == ntick and slots == set(range(npart))
+        if not fold:
+            q0, q1 = p * ns // npc, (p + 1) * ns // npc       # the piece's share of the strip's tiles (stream_task)
+            assert q1 - q0 <= cap
+            if p < npc - 1:
+                assert x0 + p not in slots
+                slots.add(x0 + p)
+    for u in (ntick, ntick + 1, ntick + 1000):
+        L.check(probe.sgpr_probe_trsm_piece(u, cap, T, out))
+        assert out[0] == T                                    # past the end: the grid's exit
+    assert slots == set(range(npart))
