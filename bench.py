@@ -352,14 +352,32 @@ def main():
     nrhs = args.nrhs if args.nrhs >= 0 else (64 if d == 3 else 0)
     rhs = None
     if nrhs > 0:
+        import torch
         Bm = np.random.default_rng(5).standard_normal((n, nrhs))
         Bm[:, 0] = z
+        # (a) right-hand sides resident in HBM (sgpr_fit_solve_rhs_dev), four solves back to back: this is the figure.  The first
+        # of them follows host work and is reported but not averaged: the first heavy launch behind an idle device runs ~13 % slow
+        # (lower shader clock AND more cycles per tile for the whole 15 ms).
+        dev = torch.device("cuda", torch.cuda.current_device())
+        B0 = torch.from_numpy(np.ascontiguousarray(Bm.T)).to(dev)      # (nrhs, n) contiguous = n x nrhs column-major
+        Bd = torch.empty_like(B0)
         ts = []
-        for _ in range(3):
-            Xs = fit.solve_rhs(Bm)
+        for _ in range(4):
+            Bd.copy_(B0)
+            torch.cuda.synchronize()
+            fit.solve_rhs_dev(Bd.data_ptr(), nrhs)
             ts.append(fit.solve_rhs_ms())
+        x0 = Bd[0].cpu().numpy()
+        # (b) the host-buffer entry (sgpr_fit_solve_rhs: B copied in and out around the same device work), for the record
+        th = []
+        for _ in range(2):
+            Xs = fit.solve_rhs(Bm)
+            th.append(fit.solve_rhs_ms())
+        del B0, Bd
         rhs = {"nrhs": nrhs, "ms": float(np.mean(ts[1:])), "ms_all": [float(v) for v in ts],
-               "column0_vs_alpha": float(np.linalg.norm(Xs[:, 0] - a) / np.linalg.norm(a))}
+               "ms_device_part_of_host_buffer_calls": [float(v) for v in th],
+               "column0_vs_alpha": float(np.linalg.norm(x0 - a) / np.linalg.norm(a)),
+               "column0_vs_alpha_host_buffers": float(np.linalg.norm(Xs[:, 0] - a) / np.linalg.norm(a))}
     # the Gram kernel alone, back to back (outside the timed region, not part of `value`): the build
     # inside a step starts on an idle chip right after the barrier and carries that warm-up
     rep = []
@@ -457,7 +475,7 @@ def main():
             "frac_hbm": gbs / HBM_PEAK_GBS, "frac_mfma": tf / MFMA_F64_PEAK_TF,
             "floor_ms_hbm": floor_hbm, "floor_ms_mfma": floor_mfma, "traffic": None,
             "algorithmic": "8 n^2 B read of L per forward + backward pair per 64 columns; 2 n^2 nrhs flop",
-            "timing": "HIP events around the pack, two solve launches and unpack; mean of the last 2 of 3 calls"}
+            "timing": "HIP events around the pack, two solve launches and unpack of sgpr_fit_solve_rhs_dev (right-hand sides resident in HBM); mean of the last 3 of 4 back-to-back calls"}
     if args.cpu_sample > 0:
         cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family if d == 1 else "A", args.cpu_sample)
         with SympFit(args.family if d == 1 else "A", qs, Ps, zs, hs, s2s) as fs:

@@ -34,8 +34,9 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 3   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
-                                3: sgpr_fit_solve_rhs_ms, sgpr_potrf_info_dev, sgpr_trim (entry points added, none changed) */
+#define SGPR_ABI_VERSION 4   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
+                                3: sgpr_fit_solve_rhs_ms, sgpr_potrf_info_dev, sgpr_trim (entry points added, none changed);
+                                4: sgpr_fit_solve_rhs_dev (added) */
 
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
@@ -154,6 +155,11 @@ int sgpr_fit_ldiag(sgpr_fit_t f, double *diag_out /* 2*n_pts, host */);
 int sgpr_fit_get_matrix(sgpr_fit_t f, double *A, size_t lda);
 /* extra right-hand sides with the cached factor: B (n x nrhs, host) overwritten */
 int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs);
+/* the same for right-hand sides that already live on the fit's device (n x nrhs, column-major, leading dimension ldb >= n,
+ * overwritten with the solution): no host copies, nothing allocated after the first call -- the solve's scratch stays with the
+ * fit.  Runs on the fit's stream (the caller makes sure B is complete there) and returns when the solve has finished.  This is
+ * the entry a predict path that builds its right-hand sides on the device calls, and the one bench.py's --nrhs leg times. */
+int sgpr_fit_solve_rhs_dev(sgpr_fit_t f, double *dB, size_t ldb, int nrhs);
 /* K*(2 x 2n_pts) rows . alpha for m test points (sympgpr.f90:75-86,112-124 with alpha cached):
  * out_p[k] = Kstar(1,:).alpha, out_q[k] = Kstar(2,:).alpha */
 int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P, double *out_p,
@@ -182,7 +188,7 @@ int sgpr_fit_eig(sgpr_fit_t f, double *w, double *c);
 int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, double *out);
 /* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
 int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms);
-/* milliseconds of the device part of the last sgpr_fit_solve_rhs (the two triangular solves with their pack / unpack passes;
+/* milliseconds of the device part of the last sgpr_fit_solve_rhs / _dev (the two triangular solves with their pack / unpack passes;
  * the host <-> device copies of B are outside): -1 when there has been none */
 int sgpr_fit_solve_rhs_ms(sgpr_fit_t f, double *ms);
 /* device pointers of the fit (for callers that own a torch / HIP context): K/L, alpha */

@@ -13,7 +13,7 @@ FIT_LOWER_ONLY, FIT_REG, FIT_BLOCK_QQ, FIT_BLOCK_PP = 1, 4, 8, 16
 MAP_WRAP_Q, MAP_WRAP_P, MAP_EXPLICIT = 1, 2, 4
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
-ABI_VERSION = 3      # include/sympgpr_hip.h: SGPR_ABI_VERSION
+ABI_VERSION = 4      # include/sympgpr_hip.h: SGPR_ABI_VERSION
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "sgpr_fit_ldiag": (C.c_int, [_vp, _dp]),
     "sgpr_fit_get_matrix": (C.c_int, [_vp, _dp, C.c_size_t]),
     "sgpr_fit_solve_rhs": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
+    "sgpr_fit_solve_rhs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "sgpr_fit_predict_rows": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp]),
     "sgpr_fit_nll_grad": (C.c_int, [_vp, _dp]),
     "sgpr_fit_nll_grad_terms": (C.c_int, [_vp, _dp]),

@@ -87,7 +87,48 @@ struct sgpr_fit {
     int info = 0;
     hipEvent_t ev[8] = {};    // build, factor, solve, solve_rhs: begin / end
     bool timed[4] = {false, false, false, false};
+    void *rhs_scratch = nullptr;      // the block solves' scratch, kept from call to call (grown on demand, freed with the fit)
+    size_t rhs_scratch_bytes = 0;
 };
+
+// scratch for a solve with nrhs right-hand sides: the fit's own block, grown when a call needs more.  (Allocating and freeing
+// ~0.8 GB per call -- n = 98304 -- put milliseconds of idle device, a synchronising hipFree among them, in front of every
+// solve; see sgpr_fit_solve_rhs_dev for what that does to the first launch behind it.)
+static int rhs_scratch(sgpr_fit_t f, int nrhs, double **out)
+{
+    const size_t need = potrs_mat_scratch(f->n, nrhs, f->dA, (size_t)f->n);
+    if (need > f->rhs_scratch_bytes) {
+        if (f->rhs_scratch) { SGPR_HIP(hipStreamSynchronize(f->st)); (void)hipFree(f->rhs_scratch); }
+        f->rhs_scratch = nullptr; f->rhs_scratch_bytes = 0;
+        SGPR_HIP(hipMalloc(&f->rhs_scratch, need ? need : 8));
+        f->rhs_scratch_bytes = need;
+    }
+    *out = static_cast<double *>(f->rhs_scratch);
+    return 0;
+}
+
+// X = L^-T L^-1 B for a device-resident B on the fit's stream, between the events of the solve_rhs stage
+static int solve_rhs_device(sgpr_fit_t f, double *dB, size_t ldb, int nrhs)
+{
+    int rc;
+    if (nrhs >= 8 || potrs_mat_uses_strips(f->n, nrhs, f->dA, (size_t)f->n)) {
+        double *dS = nullptr;
+        if ((rc = rhs_scratch(f, nrhs, &dS))) return rc;
+        SGPR_HIP(hipEventRecord(f->ev[6], f->st));
+        if ((rc = potrs_mat(f->n, f->dA, (size_t)f->n, f->work, dB, ldb, nrhs, dS, f->st))) return rc;
+        SGPR_HIP(hipEventRecord(f->ev[7], f->st));
+        if ((rc = solve_status(f->n, f->dA, (size_t)f->n, f->work, f->st))) return rc;
+    } else {
+        SGPR_HIP(hipEventRecord(f->ev[6], f->st));
+        for (int r = 0; r < nrhs; ++r) {
+            if ((rc = potrs_vec(f->n, f->dA, (size_t)f->n, f->work, dB + (size_t)r * ldb, f->st))) return rc;
+            if ((rc = solve_status(f->n, f->dA, (size_t)f->n, f->work, f->st))) return rc;   // the next solve reuses the hand-off words
+        }
+        SGPR_HIP(hipEventRecord(f->ev[7], f->st));
+    }
+    f->timed[3] = true;
+    return 0;
+}
 
 // the strip solves bound their spins; a give-up is reported at the first call that waits for the solve
 static int check_solve(sgpr_fit_t f)
@@ -352,7 +393,7 @@ int sgpr_fit_destroy(sgpr_fit_t f)
 {
     if (!f) return 0;
     for (void *p : {(void *)f->dX, (void *)f->dz, (void *)f->dA, (void *)f->dalpha,
-                    (void *)f->dscal, (void *)f->dinfo, f->work})
+                    (void *)f->dscal, (void *)f->dinfo, f->work, f->rhs_scratch})
         if (p) (void)hipFree(p);
     for (auto &e : f->ev)
         if (e) (void)hipEventDestroy(e);
@@ -663,26 +704,19 @@ int sgpr_fit_solve_rhs(sgpr_fit_t f, double *B, size_t ldb, int nrhs)
     if (rc) return rc;
     SGPR_HIP(hipMemcpy2DAsync(dB.p, n * sizeof(double), B, ldb * sizeof(double), n * sizeof(double), nrhs,
                               hipMemcpyHostToDevice, f->st));
-    if (nrhs >= 8 || potrs_mat_uses_strips(f->n, nrhs, f->dA, n)) {
-        DevBuf dS;
-        if ((rc = dS.alloc(potrs_mat_scratch(f->n, nrhs, f->dA, n)))) return rc;
-        SGPR_HIP(hipEventRecord(f->ev[6], f->st));
-        if ((rc = potrs_mat(f->n, f->dA, n, f->work, dB.as<double>(), n, nrhs, dS.as<double>(), f->st))) return rc;
-        SGPR_HIP(hipEventRecord(f->ev[7], f->st));
-        if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;
-    } else {
-        SGPR_HIP(hipEventRecord(f->ev[6], f->st));
-        for (int r = 0; r < nrhs; ++r) {
-            if ((rc = potrs_vec(f->n, f->dA, n, f->work, dB.as<double>() + (size_t)r * n, f->st))) return rc;
-            if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;   // the next solve reuses the hand-off words
-        }
-        SGPR_HIP(hipEventRecord(f->ev[7], f->st));
-    }
-    f->timed[3] = true;
+    if ((rc = solve_rhs_device(f, dB.as<double>(), n, nrhs))) return rc;
     SGPR_HIP(hipMemcpy2DAsync(B, ldb * sizeof(double), dB.p, n * sizeof(double), n * sizeof(double), nrhs,
                               hipMemcpyDeviceToHost, f->st));
     SGPR_HIP(hipStreamSynchronize(f->st));
     return 0;
+}
+
+int sgpr_fit_solve_rhs_dev(sgpr_fit_t f, double *dB, size_t ldb, int nrhs)
+{
+    if (!f || !dB || ldb < (size_t)f->n || nrhs < 0 || (((uintptr_t)dB) & 7)) { set_error("fit_solve_rhs_dev: bad arguments"); return SGPR_E_ARG; }
+    if (!f->factored) { set_error("fit_solve_rhs_dev: no valid factor"); return SGPR_E_STATE; }
+    if (nrhs == 0) return 0;
+    return solve_rhs_device(f, dB, ldb, nrhs);
 }
 
 int sgpr_fit_predict_rows(sgpr_fit_t f, int m, const double *q, const double *P, double *out_p,

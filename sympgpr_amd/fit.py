@@ -160,6 +160,13 @@ class SympFit:
         L.check(self._lib.sgpr_fit_solve_rhs(self._h, L.dptr(B), self.n, nrhs), "sgpr_fit_solve_rhs")
         return B
 
+    def solve_rhs_dev(self, dptr, nrhs, ldb=None):
+        """solve_rhs for right-hand sides that are already on the fit's device: `dptr` = device address (int) of an n x nrhs
+        column-major block of doubles -- e.g. `t.data_ptr()` of a contiguous torch.float64 tensor of shape (nrhs, n) --,
+        overwritten with the solution.  No host copies; returns when the solve has finished."""
+        L.check(self._lib.sgpr_fit_solve_rhs_dev(self._h, C.c_void_p(int(dptr)), self.n if ldb is None else int(ldb), int(nrhs)),
+                "sgpr_fit_solve_rhs_dev")
+
     def solve_rhs_ms(self):
         """Device time (ms) of the last solve_rhs: the triangular solves without the host copies of B."""
         v = C.c_double()

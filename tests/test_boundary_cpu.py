@@ -31,7 +31,7 @@ def test_ctypes_table_matches_header():
     from sympgpr_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_symbols()
     lib = _lib.load_library()
-    assert lib.sgpr_abi_version() == 3
+    assert lib.sgpr_abi_version() == 4
 
 
 def test_mirror_has_reference_call_surface():

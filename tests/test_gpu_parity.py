@@ -837,3 +837,38 @@ def test_not_positive_definite_in_the_panel_kernel(ops, n, bad):
         ops.cholesky(A)
     import re
     assert int(re.search(r"\d+", str(e.value)).group()) == bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pts,nrhs", [(300, 5), (640, 64), (1024, 70)])
+def test_solve_rhs_device_resident(n_pts, nrhs):
+    """sgpr_fit_solve_rhs_dev: the right-hand sides stay on the device (a torch tensor here), the solve's scratch stays with the
+    fit; same answer as the host-buffer entry, call after call, and column z gives alpha."""
+    import torch
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(n_pts + nrhs)
+    q, P = rng.uniform(0, 2 * np.pi, n_pts), rng.uniform(-3, 3, n_pts)
+    z = rng.standard_normal(2 * n_pts)
+    hyp, s2 = np.array([0.7, 0.9, 1.0]), 1e-2
+    with SympFit("A", q, P, z, hyp, s2) as f:
+        f.run()
+        n = f.n
+        B = rng.standard_normal((n, nrhs))
+        B[:, 0] = z
+        Xh = f.solve_rhs(B.copy())
+        dev = torch.device("cuda", torch.cuda.current_device())
+        B0 = torch.from_numpy(np.ascontiguousarray(B.T)).to(dev)
+        for _ in range(2):
+            Bd = B0.clone()
+            torch.cuda.synchronize()
+            f.solve_rhs_dev(Bd.data_ptr(), nrhs)
+            Xd = Bd.cpu().numpy().T
+            assert np.array_equal(Xd, Xh)
+        al = f.alpha()
+        assert np.linalg.norm(Xd[:, 0] - al) / np.linalg.norm(al) < 1e-10
+        # a wider leading dimension: the block sits inside a larger allocation
+        big = torch.zeros((nrhs, n + 24), dtype=torch.float64, device=dev)
+        big[:, :n] = B0
+        torch.cuda.synchronize()
+        f.solve_rhs_dev(big.data_ptr(), nrhs, ldb=n + 24)
+        assert np.array_equal(big[:, :n].cpu().numpy().T, Xh) and float(big[:, n:].abs().max()) == 0.0

@@ -1,6 +1,7 @@
 """Block-of-right-hand-sides solve (X = L^-T L^-1 B, sgpr_fit_solve_rhs) after one factorisation: device time of the two
 triangular solves, against the HBM-read floor (L read once per solve per 64 columns) and the fp64-MFMA floor (2 n^2 nrhs flop).
-    python tools/rhs_speed.py [--d D] [--nrhs 64] N [N ...]        SGPR_TRSM=rec selects round 3's recursion over the GEMM kernel"""
+    python tools/rhs_speed.py [--d D] [--nrhs 64] [--host] N [N ...]        SGPR_TRSM=rec selects round 3's recursion over the GEMM kernel
+Default: right-hand sides resident on the device (sgpr_fit_solve_rhs_dev), solves back to back; --host: the host-buffer entry."""
 import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +11,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--d", type=int, default=1)
 ap.add_argument("--nrhs", type=int, default=64)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--host", action="store_true", help="time the host-buffer entry (sgpr_fit_solve_rhs) instead of the device-resident one")
+ap.add_argument("--zero", action="store_true", help="experiment: all-zero right-hand sides (what the clock does without operand toggling)")
 ap.add_argument("npts", type=int, nargs="+")
 ap.add_argument("--tune", action="append", default=[], help="name=value experiment knobs (libsympgpr_probe.so), before anything runs")
 a = ap.parse_args()
@@ -31,12 +34,30 @@ for N in a.npts:
         rng = np.random.default_rng(5)
         B = rng.standard_normal((n, a.nrhs))
         B[:, 0] = z
+        if a.zero:
+            B[:] = 0.0
         ts = []
-        for _ in range(a.reps):
-            Xs = f.solve_rhs(B)
-            ts.append(f.solve_rhs_ms())
+        if a.host:
+            for _ in range(a.reps):
+                Xs = f.solve_rhs(B)
+                ts.append(f.solve_rhs_ms())
+            x0 = Xs[:, 0]
+        else:   # right-hand sides resident on the device, solves back to back (one untimed call first: the first heavy launch
+                # behind an idle device runs ~13 % slow)
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            B0 = torch.from_numpy(np.ascontiguousarray(B.T)).to(dev)
+            Bd = torch.empty_like(B0)
+            for r in range(a.reps + 1):
+                Bd.copy_(B0)
+                torch.cuda.synchronize()
+                f.solve_rhs_dev(Bd.data_ptr(), a.nrhs)
+                if r:
+                    ts.append(f.solve_rhs_ms())
+            x0 = Bd[0].cpu().numpy()
+            del B0, Bd
         al = f.alpha()
-        err = np.linalg.norm(Xs[:, 0] - al) / np.linalg.norm(al)
+        err = np.linalg.norm(x0 - al) / np.linalg.norm(al)
     t = min(ts)
     passes = (a.nrhs + 63) // 64
     gb = 8.0 * n * n * passes / 1e9
