@@ -9,6 +9,9 @@ from sympgpr_amd import _lib as L
 from sympgpr_amd.fit import SympFit
 from bench import synth
 
+for kv in [a for a in sys.argv[1:] if "=" in a]:      # name=value: experiment knobs (libsympgpr_probe.so), before anything runs
+    L.check(L.load_probe_library().sgpr_probe_tune(kv.split("=")[0].encode(), float(kv.split("=")[1])))
+sys.argv = [a for a in sys.argv if "=" not in a]
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 first = "--first" in sys.argv
 N = int(args[0])
