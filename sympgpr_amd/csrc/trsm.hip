@@ -101,6 +101,7 @@ struct TrsmArgs {
     int *mflag;            // per strip: complete slots (zero on entry)
     double *X;             // partial sums of the strips that are streamed in several pieces, XPART doubles each, all-ones on entry
     int piece;             // most tiles one stream task takes (piece_of)
+    int ncols;             // right-hand sides of this pass (1 .. 64): waves whose 32 columns are all padding skip their products
     int *state;            // [0] stream ticket, [1] chain ticket, [2] give-up flag
     int *ready;            // [c] strips whose quarter c is published (ticket order)
     unsigned long long *dbg;   // debug builds: 16 time stamps (100 MHz) per strip, or null
@@ -295,9 +296,10 @@ struct ChunkSteps {
 };
 template <bool AT, bool BT, class Mid>
 __device__ __forceinline__ void compute_chunk(double4_t (&acc)[2][2], const double *As, const double *Bs, int wm, int wn, int l15,
-                                              int l4, double (&pend)[4], bool have, Mid &&mid)
+                                              int l4, double (&pend)[4], bool have, Mid &&mid, bool skip = false)
 {
     constexpr int AN = LEAF + NPAD, BN = MS_NC + NPAD;
+    if (skip) { mid(); __builtin_amdgcn_sched_barrier(0); return; }      // (wave-uniform; the copies of the chunks ahead still go out)
     const unsigned aA = lds_addr(AT ? As + (32 * wm + l15) * XT_LD + l4 : As + l4 * AN + 32 * wm + l15);
     const unsigned aB = lds_addr(BT ? Bs + (32 * wn + l15) * XT_LD + l4 : Bs + l4 * BN + 32 * wn + l15);
     double f0[4];
@@ -326,6 +328,7 @@ struct Ctl {
     int *sh;               // 2 ints of LDS
     int known;             // strips known to be published in all four quarters (ticket order)
     int qbase;             // the polled streams: dependency index of the first tile of the piece
+    bool skip;             // this wave's 32 columns of the streamed products are padding (fewer than 33 right-hand sides): no MFMAs
     int tid;
     unsigned long long *dbg_wait;   // debug builds: [0] time of the first wait that had to poll, [1] the tile it was for
 };
@@ -433,11 +436,11 @@ __device__ __forceinline__ bool stream_loop(double4_t (&acc)[2][2], int ntiles, 
             if (ia < nch) { if (ROLE == 0) ca.issue(); ++ia; }
             const int lim = min(blimit, t + B_STAGES);
             while (ib < lim) { if (ROLE == 1) cb.issue(); ++ib; }
-        });
+        }, POLL && c.skip);
         sa_slot = sa_slot + 1 == A_STAGES ? 0 : sa_slot + 1;
         sb_slot = sb_slot + 1 == B_STAGES ? 0 : sb_slot + 1;
     }
-    if (nch > 0) mfma4(acc, pend);
+    if (nch > 0 && !(POLL && c.skip)) mfma4(acc, pend);
     // every wave is done with the last chunk before anybody refills the rings
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -564,7 +567,10 @@ __device__ __forceinline__ bool stream_task(const TrsmArgs &a, const Piece pc, C
         const OpStream oa{tile_ptr(q0), (unsigned)a.ldl, fwd ? (long)MS_BK * (long)a.ldl : (long)MS_BK, fwd ? 0L : -2L * LEAF};
         OpStream ob{seg_ptr(q0), (unsigned)MS_YLD, (long)MS_BK * MS_YLD, fwd ? 0L : -2L * LEAF * MS_YLD};
         if (TRSM_DBG && a.fake_b == 1) { ob.p0 = a.P + (size_t)(fwd ? 0 : T - 1) * LEAF * MS_YLD; ob.step = 0; ob.adj = 0; }   // experiment: every segment chunk from ONE cache-hot place (wrong results)
-        if (!stream_products<AT, false, true>(acc, q1 - q0, oa, ob, c, smem)) return false;
+        c.skip = 32 * wn >= a.ncols;
+        const bool ok = stream_products<AT, false, true>(acc, q1 - q0, oa, ob, c, smem);
+        c.skip = false;
+        if (!ok) return false;
     }
     stamp(2);
     // ---- RUNNING partial sums: piece p adds what piece p - 1 left (the sum of pieces 0 .. p - 1; value v of thread tid at
@@ -778,7 +784,7 @@ __global__ __launch_bounds__(MS_T) void trsm_strips_kernel(const TrsmArgs a)
     const int tid = threadIdx.x;
     const bool chain = (int)blockIdx.x < a.nchain;
     const int ntasks = chain ? 4 * a.T : a.T;
-    Ctl c{a.state, a.ready, sh, 0, 0, tid, nullptr};
+    Ctl c{a.state, a.ready, sh, 0, 0, false, tid, nullptr};
     for (;;) {
         if (tid == 0) {
             const int u = atomicAdd(a.state + (chain ? 1 : 0), 1);
@@ -932,7 +938,7 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
         SGPR_HIP(hipMemsetAsync(I1, 0xFF, 2 * img * sizeof(double), st));       // P and S of the forward solve
         if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
         SGPR_HIP(hipMemsetAsync(mflag, 0, (size_t)2 * (T + 1) * sizeof(int), st));
-        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, mflag, X, piece, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
+        TrsmArgs a{T, nchain, L, ldl, inv, I0, I1, S, M, mflag, X, piece, nc, state, state + 8, nullptr, TRSM_DBG ? (int)tune("trsm_fake_b", 0) : 0};
         const bool dbg = TRSM_DBG && getenv("SGPR_TRSM_DBG") != nullptr;
         if (dbg) { (void)hipMalloc((void **)&a.dbg, sizeof(unsigned long long) * DBGW * T); (void)hipMemset(a.dbg, 0, sizeof(unsigned long long) * DBGW * T); }
         hipLaunchKernelGGL(trsm_strips_kernel<true>, dim3(nchain + nstream), dim3(MS_T), 0, st, a);

@@ -29,6 +29,8 @@ elif [ "$1" = rhs ]; then
     timeout -k 10 300 python3 tools/rhs_speed.py --reps 3 --d 3 16384 2>&1 | grep nrhs >> $O/rhs_sizes.txt &&
     timeout -k 10 300 python3 tools/rhs_speed.py --reps 3 --nrhs 8 8192 32768 2>&1 | grep nrhs >> $O/rhs_sizes.txt &&
     timeout -k 10 300 python3 tools/rhs_speed.py --reps 3 --nrhs 16 8192 32768 2>&1 | grep nrhs >> $O/rhs_sizes.txt &&
+    timeout -k 10 300 python3 tools/rhs_speed.py --reps 3 --nrhs 32 8192 32768 2>&1 | grep nrhs >> $O/rhs_sizes.txt &&
+    timeout -k 10 300 python3 tools/rhs_speed.py --reps 3 --nrhs 32 --d 3 16384 2>&1 | grep nrhs >> $O/rhs_sizes.txt &&
     timeout -k 10 300 python3 tools/rhs_speed.py --reps 3 --nrhs 256 8192 2>&1 | grep nrhs >> $O/rhs_sizes.txt &&
     SGPR_TRSM=rec timeout -k 10 300 python3 tools/rhs_speed.py --reps 2 8192 2>&1 | grep nrhs | sed 's/^/SGPR_TRSM=rec (round 3: recursion over the GEMM kernel): /' >> $O/rhs_sizes.txt &&
     SGPR_TRSM=rec timeout -k 10 300 python3 tools/rhs_speed.py --reps 2 --d 3 16384 2>&1 | grep nrhs | sed 's/^/SGPR_TRSM=rec (round 3: recursion over the GEMM kernel): /' >> $O/rhs_sizes.txt &&
