@@ -11,9 +11,12 @@ from sympgpr_amd.fit import SympFit
 ap = argparse.ArgumentParser()
 ap.add_argument("--ntest", type=int, default=37)
 ap.add_argument("--steps", type=int, default=50)
+ap.add_argument("--tune", action="append", default=[], help="name=value experiment knobs (libsympgpr_probe.so)")
 ap.add_argument("n0", type=int, nargs="*", default=[80, 2048, 16384])
 a = ap.parse_args()
 probe = L.load_probe_library()
+for kv in a.tune:
+    L.check(probe.sgpr_probe_tune(kv.split('=')[0].encode(), float(kv.split('=')[1])))
 try:
     from oracle.oracle import Ref
     ref = Ref() if Ref.available() else None
