@@ -27,6 +27,8 @@ int sgpr_probe_gemm_debug(int bits);
 /* shader cycles per phase of one 128x128 leaf factorisation: load, diag block, panel rows,
  * trailing update, write-back, inverse diag, inverse rows, final store */
 int sgpr_probe_leaf(double *out8);
+/* cycles per step of eight dependent micro-sequences on one wave (the building blocks of the leaf's diagonal-block step) */
+int sgpr_probe_lat(double *out8);
 /* HW_REG_XCC_ID of each workgroup of a 1-D grid of 512-thread blocks (checks the tile map's `id % 8`) */
 int sgpr_probe_xcc(int nblocks, int *host_out);
 /* the same on a stream restricted by a CU mask (hipExtStreamCreateWithCUMask): out[2b] = XCC id, out[2b+1] = HW_ID */

@@ -120,6 +120,7 @@ PROBE_SIGNATURES = {
     "sgpr_probe_gemm": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "sgpr_probe_gemm_debug": (C.c_int, [C.c_int]),
     "sgpr_probe_leaf": (C.c_int, [_dp]),
+    "sgpr_probe_lat": (C.c_int, [_dp]),
     "sgpr_probe_cumask": (C.c_int, [C.POINTER(C.c_uint), C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "sgpr_probe_xcc": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "sgpr_probe_hbm_write": (C.c_int, [C.c_size_t, C.c_int, _dp]),

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(LT) void fit_batch_kernel(const BatchArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // ---- L11, X11 = inv(L11)
-        leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), n1, A, ld, inv, a.info + b, 0, (int)LEAF_FACTOR,
+        leaf_body(s, n1, A, ld, inv, a.info + b, 0, (int)LEAF_FACTOR,
                   nullptr);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(LT) void fit_batch_kernel(const BatchArgs a)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), n2, A + n1 + n1 * ld, ld, inv + LEAF * LEAF,
+            leaf_body(s, n2, A + n1 + n1 * ld, ld, inv + LEAF * LEAF,
                       a.info + b, n1, (int)LEAF_FACTOR, nullptr);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -36,8 +36,8 @@ __global__ __launch_bounds__(LT) void leaf_kernel(int nb, double *A, size_t lda,
 {
     __shared__ double s[LEAF_LDS];
     // a full leaf gets its loop bounds at compile time (59 us; with the run-time order of a partial leaf 64)
-    if (nb == LEAF) leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, A, lda, inv, dinfo, goff, mode, stamps);
-    else            leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), nb, A, lda, inv, dinfo, goff, mode, stamps);
+    if (nb == LEAF) leaf_body(s, (int)LEAF, A, lda, inv, dinfo, goff, mode, stamps);
+    else            leaf_body(s, nb, A, lda, inv, dinfo, goff, mode, stamps);
 }
 
 // b(nb) := inv(L) b  or  inv(L)^T b   (inv: LEAF x LEAF lower, zero upper).
@@ -646,7 +646,7 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (dbg) a.dbg[16 * g + 4] = __builtin_amdgcn_s_memrealtime();
-        leaf_body(s, s + LEAF * LLD, s + LEAF * LLD + PW * (PW + 1), (int)LEAF, tileptr(g, g), a.lda,
+        leaf_body(s, (int)LEAF, tileptr(g, g), a.lda,
                   a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr,
                   a.flags + E0 + g, g > 0);
         panel_publish(a.flags + 2 + g);

@@ -34,11 +34,11 @@ __device__ __forceinline__ void store_wt(double *p, double v)
 //            lower triangle in 4x4 register tiles;
 //   inverse: the eight 16x16 diagonal blocks at once, then recursive doubling (16 -> 32 -> 64 -> 128):
 //            X21 = -X22 L21 X11 for every pair of a level on the matrix cores.
-__device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sInv /* PW * (PW + 1) */,
-                                          double *sRl /* PW: 1 / L11(j,j) of the current panel */, int nb,
+__device__ __forceinline__ void leaf_body(double *s /* LEAF_LDS doubles: the block, then two PW x (PW + 1) buffers */, int nb,
                                           double *A, size_t lda, double *inv, int *dinfo, int goff, int mode,
                                           unsigned long long *stamps, int *early_flag = nullptr, bool preloaded = false)
 {
+    double *const sInv = s + LEAF * LLD;   // inv(L11) of the current panel and of the next one (double-buffered)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // Rows / columns from nend on are the identity padding: nothing is computed there (a batched fit of order 80
@@ -80,67 +80,97 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
     mark(0);
 
     if (mode == LEAF_FACTOR) {
-        const int wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-        // (A) 16x16 diagonal block at c0, one wave: lane r holds row r in registers; the pivot of
-        // column j comes from lane j by v_readlane, 1/sqrt by the hardware estimate + two Newton
-        // steps, the scaled column is published through a 16-double LDS strip and read back as
-        // broadcasts (15 independent reads instead of a chain of dependent cross-lane shuffles).
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, l4 = lane >> 4;
         // L goes out to A as its entries become final (write-through when it is handed over early)
         auto put = [&](double *dst, double v) {
             if (early_flag) store_wt(dst, v);
             else *dst = v;
         };
-        // the factored 16 x 16 diagonal block at c0, two entries per helper thread t < 128, out of LDS
-        auto put_diag = [&](int c0, int t) {
-            const int i = t & 15, c = (t >> 4) * 2;
-            if (c0 + i < nb) {
-                if (c <= i) put(A + (size_t)(c0 + i) + (size_t)(c0 + c) * lda, s[(c0 + c) * LLD + c0 + i]);
-                if (c + 1 <= i) put(A + (size_t)(c0 + i) + (size_t)(c0 + c + 1) * lda, s[(c0 + c + 1) * LLD + c0 + i]);
-            }
+        auto bcast = [&](double v, int ln) {              // v of lane ln, wave-uniform (compile-time ln)
+            const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), ln);
+            const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), ln);
+            return __hiloint2double((int)hi, (int)lo);
         };
-        auto diag_factor = [&](int c0) {
-            double a[PW];
+        double mneg[PW];                                  // A-operand mask of column step j of (A), as a factor
 #pragma unroll
-            for (int c = 0; c < PW; ++c)
-                a[c] = (lane < PW && c <= lane) ? s[(c0 + c) * LLD + c0 + lane] : 0.0;
-            bool bad = false;
-            int badj = 0;
-            auto pivot = [&](double v, int j, double &d, double &rl) {   // d = v on lane j; rl = 1/sqrt(d)
-                const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), j);
-                const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), j);
-                d = __hiloint2double((int)hi, (int)lo);
-                rl = __builtin_amdgcn_rsq(d);
-                rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
-                rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
-            };
-            double d, rl;
-            pivot(a[0], 0, d, rl);
+        for (int j = 0; j < PW; ++j) mneg[j] = (l4 == (j & 3) && l15 > j) ? -1.0 : 0.0;
+        auto rsqrt_nr = [&](double d) {                   // hardware estimate + two Newton steps
+            double rl = __builtin_amdgcn_rsq(d);
+            rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
+            rl = rl * __builtin_fma(-0.5 * d * rl, rl, 1.5);
+            return rl;
+        };
+        // The 16 x 16 diagonal block at c0 as a FULL symmetric tile in the accumulator layout of v_mfma_f64_16x16x4
+        // (element r of lane (l15, l4) = D(4 r + l4, l15)), mirrored out of the lower triangle of s.
+        auto load_diag = [&](int c0) {
+            double4_t D;
 #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * r + l4, j = l15;
+                D[r] = s[(c0 + (i >= j ? j : i)) * LLD + c0 + (i >= j ? i : j)];
+            }
+            return D;
+        };
+        // (A) the diagonal block, ONE wave, in registers from start to end.  Column j of a symmetric tile is its row j, and
+        // row j sits in the lanes l4 == (j & 3), element j >> 2, at l15 = row index: exactly where BOTH operands of a
+        // rank-1 v_mfma_f64_16x16x4 (k-slot j & 3) take it from.  So a column step is: scale by 1/sqrt(pivot), one MFMA --
+        // no cross-lane traffic, no LDS round trip; the next pivot (two v_readlane pairs + its 1/sqrt chain) runs beside
+        // the MFMA.  Only the A operand is masked (k-slot and rows below j: mneg[j] = -1 there, 0 elsewhere): whatever
+        // the other lanes hold is multiplied by zero, and rows / columns <= j of D are dead.  An identity tile takes the
+        // same eliminations with its rows scaled at the end: it ends as inv(L11), which is what the panel rows are
+        // multiplied by (B) and what the early hand-off / the inverse phase start from.
+        auto diag_factor = [&](int c0, double4_t D, double *sI) {
+            double4_t X;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[r] = (4 * r + l4 == l15) ? 1.0 : 0.0;
+            double rl = rsqrt_nr(bcast(D[0], 0));
+            double lv[PW], rls[PW];                                            // kept in registers: LDS traffic inside the loop
+#pragma unroll                                                                 // cost 100 cycles per column (tools/probe_lat.py)
             for (int j = 0; j < PW; ++j) {
-                if (!(d > 0.0) && !bad) { bad = true; badj = j; }
-                a[j] = (lane == j) ? d * rl : a[j] * rl;
-                if (lane == j) sRl[j] = rl;
-                // the next pivot needs only lane j+1's own values (a[j+1] - a[j]^2): its 1/sqrt chain
-                // runs beside the column update below
-                double dn = 0.0, rn = 0.0;
-                if (j + 1 < PW) pivot(__builtin_fma(-a[j], a[j], a[j + 1]), j + 1, dn, rn);
-                // column update a(r,c) -= L(r,j) L(c,j): L(c,j) is a[j] of lane c -- read across the wave into
-                // scalar registers (v_readlane), not through an LDS strip and its write -> wait -> read round trip
-#pragma unroll
-                for (int c = j + 1; c < PW; ++c) {
-                    const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(a[j]), c);
-                    const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(a[j]), c);
-                    a[c] = __builtin_fma(-a[j], __hiloint2double((int)hi, (int)lo), a[c]);
+                const int g = j & 3, rj = j >> 2;
+                const double v = D[rj] * rl;                                   // lanes l4 == g: L(c0 + l15, c0 + j)
+                const double x = X[rj] * rl;                                   // lanes l4 == g: row j of inv(L11)
+                double rn = 0.0;
+                if (j + 1 < PW) {
+                    const double dnext = bcast(D[(j + 1) >> 2], (j + 1) + 16 * ((j + 1) & 3));
+                    const double lnext = bcast(v, (j + 1) + 16 * g);
+                    rn = rsqrt_nr(__builtin_fma(-lnext, lnext, dnext));
                 }
-                d = dn;
+                lv[j] = v;
+                rls[j] = rl;
+                const double nv = v * mneg[j];
+                D = __builtin_amdgcn_mfma_f64_16x16x4f64(nv, v, D, 0, 0, 0);
+                X = __builtin_amdgcn_mfma_f64_16x16x4f64(nv, x, X, 0, 0, 0);
                 rl = rn;
             }
-            if (bad && lane == 0 && *dinfo == 0) *dinfo = goff + c0 + badj + 1;
-            if (lane < PW) {
+            // L11 out to LDS: column j sits in the lanes l4 == (j & 3) (above the diagonal: dead values, never read)
 #pragma unroll
-                for (int c = 0; c < PW; ++c)
-                    if (c <= lane) s[(c0 + c) * LLD + c0 + lane] = a[c];
+            for (int g = 0; g < 4; ++g) {
+                if (l4 == g) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) s[(c0 + 4 * m + g) * LLD + c0 + l15] = lv[4 * m + g];
+                }
             }
+            // inv(L11): row c of the identity tile times 1 / L11(c, c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double rr = l4 == 0 ? rls[4 * r] : l4 == 1 ? rls[4 * r + 1] : l4 == 2 ? rls[4 * r + 2] : rls[4 * r + 3];
+                sI[(4 * r + l4) * (PW + 1) + l15] = X[r] * rr;                 // sI[c][i] = inv(L11)(c, i)
+            }
+            // a pivot that was not positive leaves NaN from its column on: LAPACK's info is the first such column
+            const double ljj = s[(c0 + l15) * LLD + c0 + l15];
+            const unsigned long long okm = __ballot(ljj > 0.0) & 0xffffull;
+            if (okm != 0xffffull && lane == 0 && *dinfo == 0) *dinfo = goff + c0 + __builtin_ctzll(~okm) + 1;
+        };
+        // (B) sixteen panel rows at row0: X = R inv(L11)^T, four MFMAs
+        auto solve_tile = [&](int c0, int row0, const double *sI) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < PW / 4; ++kk)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[(c0 + 4 * kk + l4) * LLD + row0 + l15], sI[l15 * (PW + 1) + 4 * kk + l4],
+                                                           acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[(c0 + l15) * LLD + row0 + 4 * r + l4] = acc[r];
         };
         // (C) one 16x16 tile of the trailing update on the matrix cores: k = 16 = four
         // v_mfma_f64_16x16x4_f64; both operands are "row contiguous, k strided" reads of the
@@ -155,60 +185,65 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[(j0 + l15) * LLD + i0 + 4 * r + l4] -= acc[r];  // D(i,j): j = lane&15, i = 4r + lane>>4
         };
+        // The finished columns c0 .. c0+15 go out to A (threads t of nth; rows fastest: 512-byte runs), and the diagonal
+        // block's place in s takes inv(L11): after the last panel s is what the inverse phase starts from.
+        auto put_panel = [&](int c0, int t, int nth, const double *sI) {
+            for (int e = t; e < PW * PW; e += nth) {
+                const int i = e & 15, c = e >> 4;
+                if (i >= c) {
+                    if (c0 + i < nb) put(A + (size_t)(c0 + i) + (size_t)(c0 + c) * lda, s[(c0 + c) * LLD + c0 + i]);
+                    s[(c0 + c) * LLD + c0 + i] = sI[i * (PW + 1) + c];
+                }
+            }
+            const int top = min(nend, nb);
+            for (int c = t >> 6; c < PW; c += nth >> 6)           // (nth is a multiple of 64: a wave per column, 64 rows a go)
+                for (int i = c0 + PW + (t & 63); i < top; i += 64) put(A + (size_t)i + (size_t)(c0 + c) * lda, s[(c0 + c) * LLD + i]);
+        };
 
-        if (wave == 0) diag_factor(0);
+        if (wave == 0) diag_factor(0, load_diag(0), sInv);
         __syncthreads();
         mark(1);
         for (int c0 = 0; c0 < nend - PW; c0 += PW) {
             const int r0 = c0 + PW;
             const int rem = nend - r0;
-            // ---- (B) panel rows: r := r L11^-T, one row per thread
-            if (tid < rem) {
-                const int i = r0 + tid;
-                double r[PW];
+            const int nt = rem / 16;
+            const double *sI = sInv + ((c0 / PW) & 1) * PW * (PW + 1);
+            double *sIn = sInv + (((c0 / PW) & 1) ^ 1) * PW * (PW + 1);
+            // ---- (B) panel rows on the matrix cores.  Wave 0 takes the rows of the NEXT diagonal block and goes on to update
+            // that block in its registers (its own X out of LDS again as both operands): it enters (A) of the next panel
+            // right behind the barrier.
+            double4_t Dn = {0.0, 0.0, 0.0, 0.0};
+            if (wave == 0) {
+                solve_tile(c0, r0, sI);
+                Dn = load_diag(r0);
 #pragma unroll
-                for (int c = 0; c < PW; ++c) r[c] = s[(c0 + c) * LLD + i];
-#pragma unroll
-                for (int j = 0; j < PW; ++j) {
-                    double acc = r[j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) acc = __builtin_fma(-r[k], s[(c0 + k) * LLD + c0 + j], acc);
-                    r[j] = acc * sRl[j];
+                for (int kk = 0; kk < PW / 4; ++kk) {
+                    const double xa = s[(c0 + 4 * kk + l4) * LLD + r0 + l15];
+                    Dn = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa, xa, Dn, 0, 0, 0);
                 }
-#pragma unroll
-                for (int c = 0; c < PW; ++c) s[(c0 + c) * LLD + i] = r[c];
-                if (i < nb) {
-#pragma unroll
-                    for (int c = 0; c < PW; ++c) put(A + (size_t)i + (size_t)(c0 + c) * lda, r[c]);
-                }
-            } else if (tid >= LT / 2) {
-                put_diag(c0, tid - LT / 2);            // threads 128.. never have a row here: the diagonal block goes out
+            } else {
+                for (int t = wave; t < nt; t += LT / 64 - 1) solve_tile(c0, r0 + 16 * t, sI);
             }
             __syncthreads();
             mark(2);
-            // ---- (C) trailing update, with the NEXT diagonal block factored underneath it: wave 0
-            // updates tile (0,0) first and goes straight on to (A) of the next panel while waves
-            // 1-3 update the other tiles.
-            const int nt = rem / 16;
-            const int ntile = nt * (nt + 1) / 2;
+            // ---- (C) trailing update by waves 1-3, with the NEXT diagonal block factored underneath it by wave 0
             if (wave == 0) {
-                update_tile(c0, r0, r0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                diag_factor(r0);
+                diag_factor(r0, Dn, sIn);
             } else {
-                for (int idx = wave; idx < ntile; idx += LT / 64 - 1) {
-                    int ti = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                    while (ti * (ti + 1) / 2 > idx) --ti;
-                    while ((ti + 1) * (ti + 2) / 2 <= idx) ++ti;
-                    const int tj = idx - ti * (ti + 1) / 2;
+                put_panel(c0, tid - 64, LT - 64, sI);
+                // lower tiles (ti, tj) in row-major order, every third one from this wave's start; (0, 0) is wave 0's
+                int ti = 1, tj = wave - 1;                        // positions 1, 2, 3 of the order are (1,0), (1,1), (2,0)
+                if (tj > ti) { tj = 0; ++ti; }
+                while (ti < nt) {
                     update_tile(c0, r0 + 16 * ti, r0 + 16 * tj);
+                    tj += LT / 64 - 1;
+                    while (tj > ti) { tj -= ti + 1; ++ti; }
                 }
             }
             __syncthreads();
             mark(3);
         }
-        if (tid >= LT / 2) put_diag(nend - PW, tid - LT / 2);
+        put_panel(nend - PW, tid, LT, sInv + (((nend - PW) / PW) & 1) * PW * (PW + 1));
         __syncthreads();
         mark(4);
     }
@@ -216,7 +251,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
     // ---- inverse (LAPACK dtrtri order, last panel first); only the lower triangle of s is read.
     // (I0) all eight 16x16 diagonal blocks are inverted at once, in place: 128 threads, one column
     //      of one block each (x = solve L11 x = e_c), values held in registers across the barrier.
-    {
+    if (mode != LEAF_FACTOR) {        // (the factorisation leaves inv(L11) in place of every diagonal block by itself)
         const int blk = tid >> 4, c = tid & 15, d0 = blk * PW;
         double x[PW];
         if (tid < 128) {
@@ -333,7 +368,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF * LLD */, double *sI
         for (int i = 0; i < 8; ++i) stamps[i] = ph[i];
 }
 
-constexpr int LEAF_LDS = LEAF * LLD + PW * (PW + 1) + PW;   // doubles of LDS leaf_body needs
+constexpr int LEAF_LDS = LEAF * LLD + 2 * PW * (PW + 1);   // doubles of LDS leaf_body needs
 
 }  // namespace leaf
 }  // namespace sgpr

@@ -219,6 +219,123 @@ extern "C" int sgpr_probe_gemm(int m, int n, int k, int lower, double *out4)
 }
 
 // Diagnostic: phase cycle counts of one 128x128 leaf factorisation (out8, shader cycles)
+
+// Latency census of the building blocks of the leaf's 16 x 16 diagonal-block step (leaf.h, (A)): each variant runs 16
+// dependent "column steps" on ONE wave (the other three of the workgroup idle, as in the leaf) between two s_memtime.
+namespace sgpr { namespace {
+template <int V>
+__global__ __launch_bounds__(256) void lat_probe_kernel(double *io, unsigned long long *cyc)
+{
+    __shared__ double sh[64];
+    __shared__ double big[16 * 130];
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    if (threadIdx.x >= 64) return;
+    double mneg[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) mneg[j] = (l4 == (j & 3) && l15 > j) ? -1.0 : 0.0;
+    double4_t D, X;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { D[r] = (4 * r + l4 == l15) ? 4.0 + 0.01 * l15 : 1.0 / (2.0 + l15 + 4 * r + l4); X[r] = (4 * r + l4 == l15) ? 1.0 : 0.0; }
+    double rl = io[0], acc = io[1];
+    auto bcast = [&](double v, int ln) {
+        const unsigned lo = __builtin_amdgcn_readlane((int)__double2loint(v), ln);
+        const unsigned hi = __builtin_amdgcn_readlane((int)__double2hiint(v), ln);
+        return __hiloint2double((int)hi, (int)lo);
+    };
+    auto nr = [&](double d) {
+        double r = __builtin_amdgcn_rsq(d);
+        r = r * __builtin_fma(-0.5 * d * r, r, 1.5);
+        r = r * __builtin_fma(-0.5 * d * r, r, 1.5);
+        return r;
+    };
+    unsigned long long t0, t1;
+    // (the stamps are tied to the data flow: the loop's inputs pass through the first asm, its results into the second)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "+v"(rl), "+v"(acc), "+v"(D), "+v"(X) : : "memory");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int rj = j >> 2;
+        if (V == 0) {            // one dependent MFMA per step, operand from the accumulator (scaled)
+            const double v = D[rj] * rl;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, D, 0, 0, 0);
+        } else if (V == 1) {     // two MFMAs per step (second independent of the first)
+            const double v = D[rj] * rl, x = X[rj] * rl;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, D, 0, 0, 0);
+            X = __builtin_amdgcn_mfma_f64_16x16x4f64(v, x, X, 0, 0, 0);
+        } else if (V == 2) {     // the pivot chain alone: 2 readlane pairs, fma, rsq, two Newton steps
+            const double a = bcast(acc, (j + 1) & 63), b = bcast(rl, (j + 17) & 63);
+            rl = nr(__builtin_fma(-b, b, a + 5.0));
+            acc += rl;
+        } else if (V == 3) {     // rsq alone, dependent
+            rl = __builtin_amdgcn_rsq(rl + 1.0);
+        } else if (V == 4) {     // eight dependent DP fma
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rl = __builtin_fma(rl, acc, 0.5);
+        } else if (V == 5) {     // readlane pair -> VALU use, dependent
+            rl = bcast(rl, (j + 1) & 63) + acc;
+        } else if (V == 6) {     // LDS write -> read round trip, same wave
+            sh[lane] = rl;
+            rl = sh[(lane + 1) & 63] + 1.0;
+        } else if (V >= 8) {     // the leaf's loop: 8 = as it is, 9 = without the identity tile, 10 = without LDS writes, 11 = 9 without LDS writes
+            const int g = j & 3;
+            const double v = D[rj] * rl;
+            const double x = X[rj] * rl;
+            double rn = 0.0;
+            if (j + 1 < 16) {
+                const double dnext = bcast(D[(j + 1) >> 2], (j + 1) + 16 * ((j + 1) & 3));
+                const double lnext = bcast(v, (j + 1) + 16 * g);
+                rn = nr(__builtin_fma(-lnext, lnext, dnext));
+            }
+            if (V == 8 || V == 9) {
+                if (l4 == g) big[j * 130 + l15] = v;
+                sh[j] = rl;
+            }
+            const double nv = v * mneg[j];
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(nv, v, D, 0, 0, 0);
+            if (V == 8 || V == 10) X = __builtin_amdgcn_mfma_f64_16x16x4f64(nv, x, X, 0, 0, 0);
+            rl = rn;
+        } else if (V == 7) {     // MFMA with result read through a readlane and back into the next operand
+            const double v = D[rj] * rl;
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, D, 0, 0, 0);
+            rl = bcast(D[0], 0) * 1e-3;
+        }
+    }
+    double ssum = rl + acc + D[0] + D[1] + D[2] + D[3] + X[0] + X[1] + X[2] + X[3];
+    asm volatile("s_nop 0\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "+v"(ssum) : : "memory");
+    if (lane == 0) cyc[V] = t1 - t0;
+    if (ssum == 12345.678) io[2] = ssum + big[lane] + sh[lane];
+}
+} }
+
+extern "C" int sgpr_probe_lat(double *out8 /* 12 values */)
+{
+    double *io = nullptr;
+    unsigned long long *cyc = nullptr;
+    SGPR_HIP(hipMalloc((void **)&io, 64));
+    SGPR_HIP(hipMalloc((void **)&cyc, 128));
+    const double h[3] = {0.49, 1.25, 0.0};
+    SGPR_HIP(hipMemcpy(io, h, sizeof(h), hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<0>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<1>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<2>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<3>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<4>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<5>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<6>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<7>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<8>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<9>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<10>), dim3(1), dim3(256), 0, 0, io, cyc);
+        hipLaunchKernelGGL((sgpr::lat_probe_kernel<11>), dim3(1), dim3(256), 0, 0, io, cyc);
+        SGPR_HIP(hipDeviceSynchronize());
+    }
+    unsigned long long hs[12];
+    SGPR_HIP(hipMemcpy(hs, cyc, 96, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 12; ++i) out8[i] = (double)hs[i] / 16.0;
+    (void)hipFree(io); (void)hipFree(cyc);
+    return 0;
+}
+
 extern "C" int sgpr_probe_leaf(double *out8)
 {
     const int n = LEAF;
