@@ -204,7 +204,14 @@ constexpr int PANEL_G_MAX = 256;                // workgroups (each holds a whol
 struct PanelArgs {
     double *P;        // panel origin: element (k0, k0) of the matrix
     size_t lda;
-    int R, W, G;      // row strips (incl. the W diagonal ones), leaf columns, workgroups
+    int R, W, G;      // row strips (incl. the W diagonal ones), leaf columns, workgroups (diagonal strips + strips below)
+    int NH;           // helper workgroups, tickets W .. W+NH-1 (0 or (W-1)(W-2)/2): one per tile (g, c'), 1 <= c' < g < W, of the
+                      // diagonal block -- it applies the columns c < c' to that tile so that strip g does not have to
+    int below_early;  // strips below: every column by the blocked solve on the early hand-off (not only the last one)
+    int tiles;        // rows below the diagonal block TILE by tile (r, c') instead of strip by strip: the G - W workgroups behind the
+                      // helpers draw tiles in column-major order; row r's progress (columns solved) in flags[PFLAG_STRIDE + r - W]
+                      // -- the words of the panel's second leaf column, which no panel kernel of this schedule uses (needs W >= 2,
+                      // R - W < PFLAG_STRIDE)
     double *inv;      // leaf inverses of this panel's W leaves (LEAF x LEAF each)
     int *dinfo;
     int goff;         // global index of the panel's first row / column (LAPACK info)
@@ -600,10 +607,33 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
             for (int c = 0; c <= g; ++c) idx[c] = (vi * a.ver_ld + a.ver_j0 + c) * (int)cholq::VS;
             if (!panel_wait_ge(a.ver, idx, g + 1, a.ver_need, a.dinfo, sh + 1, a.abort)) return false;
         }
+        // Tiles (g, c'), 1 <= c' < g: whoever gets there first.  A helper workgroup that is running has put 1 into the
+        // tile's word (3 once the tile carries every column c < c'); this strip takes the others for itself (2) and
+        // updates them behind each of its solves as before -- it never waits for a workgroup that has not started.
+        unsigned helped = 0;
+        auto claim_tiles = [&]() {                      // (behind this strip's first solve: a helper that is going to run has started by now)
+            if (tid == 0) {
+                unsigned m = 0;
+                for (int cp = 1; cp < g; ++cp) {
+                    const int old = atomicCAS(a.flags + F0 + cp * PW_MAX + g, 0, 2);
+                    if (old == 1 || old == 3) m |= 1u << cp;
+                }
+                sh[1] = (int)m;
+            }
+            __syncthreads();
+            helped = (unsigned)sh[1];
+            __syncthreads();
+        };
+        auto wait_helper = [&](int cp) -> bool {       // tile (g, cp) has taken the columns before cp?
+            if (!((helped >> cp) & 1u)) return true;
+            idx[0] = F0 + cp * PW_MAX + g;
+            return panel_wait_ge(a.flags, idx, 1, 3, a.dinfo, sh + 1, a.abort);
+        };
         for (int c = 0; c + 1 < g; ++c) {
             double *X = tileptr(g, c);
             XTile x;
             CTile cd;
+            if (!wait_helper(c)) return false;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the updates this workgroup applied to (g,c) have
             __syncthreads();                                      // landed, whichever wave stored them
             trsm_prefetch(X, a.lda, x);
@@ -617,17 +647,21 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
             // strips c' in (c, g)
             panel_publish_wt(a.flags + F0 + g * PW_MAX + c);
             diag_update_global(s, x, cd, tileptr(g, g), a.lda);
+            if (c == 0 && a.NH > 0) claim_tiles();
             int cnt = 0;
-            for (int cc = c + 1; cc < g; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
+            for (int cc = c + 1; cc < g; ++cc)
+                if (!((helped >> cc) & 1u)) idx[cnt++] = F0 + cc * PW_MAX + c;
             if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return false;
             for (int t = 1; t < g - c; ++t)
-                panel_product(s, -1.0, X, a.lda, tileptr(c + t, c), a.lda, 1.0, tileptr(g, c + t), a.lda);
+                if (!((helped >> (c + t)) & 1u))
+                    panel_product(s, -1.0, X, a.lda, tileptr(c + t, c), a.lda, 1.0, tileptr(g, c + t), a.lda);
         }
         if (g > 0) {
             const int c = g - 1;
             double *X = tileptr(g, c);
             XTile x;
             CTile cd;
+            if (!wait_helper(c)) return false;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's updates of (g,c) and (g,g) have landed
             __syncthreads();
             trsm_prefetch(X, a.lda, x);
@@ -648,7 +682,7 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
         if (dbg) a.dbg[16 * g + 4] = __builtin_amdgcn_s_memrealtime();
         leaf_body(s, (int)LEAF, tileptr(g, g), a.lda,
                   a.inv + (size_t)g * LEAF * LEAF, a.dinfo, a.goff + g * LEAF, (int)LEAF_FACTOR, nullptr,
-                  a.flags + E0 + g, g > 0);
+                  a.flags + E0 + g, g > 0, dbg ? a.dbg + 16 * g + 11 : nullptr);
         panel_publish(a.flags + 2 + g);
         // task-queue driver: "something moved" (the workers drain their kernel instance when nothing does, cholq.h)
         if (a.abort && tid == 0)
@@ -657,51 +691,127 @@ __device__ __forceinline__ bool panel_strip(const PanelArgs &a, const int g, dou
         if (cen && tid == 0) cen[2] = __builtin_amdgcn_s_memrealtime();
         return true;
     }
-    // ---- strips below the diagonal block, shared round-robin by the other workgroups: products with inv(L_cc)
+    if (g < W + a.NH) {
+        // ---- a helper: tile (gg, cp) of the diagonal block takes the columns c < cp as their rows X(gg, c), X(cp, c)
+        // are published by the two diagonal strips (tickets 0 .. W-1: they started before this workgroup or are waited
+        // for like the strips below wait for them)
+        int h = g - W, cp = 1, gg = 2;
+        while (h >= W - 1 - cp) { h -= W - 1 - cp; ++cp; }
+        gg = cp + 1 + h;
+        int *word = a.flags + F0 + cp * PW_MAX + gg;
+        if (tid == 0) sh[1] = atomicCAS(word, 0, 1);
+        __syncthreads();
+        const int old = sh[1];
+        __syncthreads();
+        if (old != 0) return true;                      // strip gg was there first and does it itself
+        if (a.ver) {
+            idx[0] = ((a.ver_i0 + (gg >> 1)) * a.ver_ld + a.ver_j0 + cp) * (int)cholq::VS;
+            if (!panel_wait_ge(a.ver, idx, 1, a.ver_need, a.dinfo, sh + 1, a.abort)) return false;
+        }
+        for (int c = 0; c < cp; ++c) {
+            idx[0] = F0 + gg * PW_MAX + c;
+            idx[1] = F0 + cp * PW_MAX + c;
+            if (!panel_wait(a.flags, idx, 2, a.dinfo, sh + 1, a.abort)) return false;
+            panel_product(s, -1.0, tileptr(gg, c), a.lda, tileptr(cp, c), a.lda, 1.0, tileptr(gg, cp), a.lda);
+        }
+        panel_publish_val(word, 3);
+        return true;
+    }
+    const int gb = g - a.NH;
+    if (a.tiles) {
+        // ---- one tile (r, cp) of the rows below: left-looking -- it takes the columns c < cp as X(r, c) (its row's
+        // progress word) and L(cp, c) (diagonal strip cp) appear, is solved on the early hand-off of leaf cp, and moves its
+        // row's progress on.  Waits only for smaller tickets (same row, earlier column) and for diagonal strips.
+        // Tiles are DRAWN in column-major order from a counter (the last word of the same spare block), so a tile's
+        // predecessors were drawn before it by workgroups that are running or done -- whatever the number of workgroups.
+        const int nbel = R - W, ntiles = nbel * W;
+        int *const counter = a.flags + 2 * PFLAG_STRIDE - 1;
+        for (;;) {
+            if (tid == 0) sh[1] = atomicAdd(counter, 1);
+            __syncthreads();
+            const int q = sh[1];
+            __syncthreads();
+            if (q >= ntiles) return true;
+            const int cp = q / nbel, r = W + q % nbel;
+            const int pword = PFLAG_STRIDE + (r - W);
+            if (a.ver) {
+                idx[0] = ((a.ver_i0 + (r >> 1)) * a.ver_ld + a.ver_j0 + cp) * (int)cholq::VS;
+                if (!panel_wait_ge(a.ver, idx, 1, a.ver_need, a.dinfo, sh + 1, a.abort)) return false;
+            }
+            for (int c = 0; c < cp; ++c) {
+                idx[0] = pword;
+                if (!panel_wait_ge(a.flags, idx, 1, c + 1, a.dinfo, sh + 1, a.abort)) return false;
+                idx[0] = F0 + cp * PW_MAX + c;
+                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
+                panel_product(s, -1.0, tileptr(r, c), a.lda, tileptr(cp, c), a.lda, 1.0, tileptr(r, cp), a.lda);
+            }
+            {
+                double *X = tileptr(r, cp);
+                XTile x;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                trsm_prefetch(X, a.lda, x);
+                idx[0] = E0 + cp;
+                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
+                trsm_solve(s, tileptr(cp, cp), a.inv + (size_t)cp * LEAF * LEAF, a.lda, x);
+                trsm_store(X, a.lda, x);
+            }
+            // X went out write-through: drained stores, the barrier, then the row's progress word (as panel_publish_wt)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store((gint *)(a.flags + pword), cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cp == W - 1) {
+                if (a.tver) panel_publish_val(a.tver + (size_t)(a.tver_r0 + r) * cholq::VS, a.tver_val);
+                if (a.abort && tid == 0)
+                    __hip_atomic_fetch_add((gint *)(a.abort + (cholq::Q_PROG - cholq::Q_ABORT)), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // ---- strips below the diagonal block, shared round-robin by the other workgroups
     const int nw = G - W;
-    const int r_first = W + (g - W), r_step = nw > 0 ? nw : R;
+    const int r_first = W + (gb - W), r_step = nw > 0 ? nw : R;
     if (a.ver) {
         // task-queue driver: one strip per workgroup here; its W tiles carry the updates of every earlier panel?
         const int vi = a.ver_i0 + (r_first >> 1);
         for (int c = 0; c < W; ++c) idx[c] = (vi * a.ver_ld + a.ver_j0 + c) * (int)cholq::VS;
         if (r_first < R && !panel_wait_ge(a.ver, idx, W, a.ver_need, a.dinfo, sh + 1, a.abort)) return false;
     }
+    const bool below_early = a.below_early != 0;
     for (int c = 0; c < W; ++c) {
-        bool have_inv = false, have_rows = false;
+        bool have_inv = false, have_early = false, have_rows = false;
         for (int r = r_first; r < R; r += r_step) {
             double *X = tileptr(r, c);
-            if (c == W - 1) {
-                // the last column: nothing follows the solve, and the kernel ends with it -- take the blocked solve,
-                // which can start on E[c], ~20 us before the leaf's full inverse is there
+            if (c == W - 1 || below_early) {
+                // the blocked solve, which can start on E[c], ~20 us before the leaf's full inverse is there (12 us
+                // against the 20 of a staged product with the inverse); the updates of the later columns follow below
                 XTile x;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 trsm_prefetch(X, a.lda, x);
-                if (!have_inv) {
+                if (!have_early) {
                     idx[0] = E0 + c;
                     if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
-                    have_inv = true;
+                    have_early = true;
                 }
                 trsm_solve(s, tileptr(c, c), a.inv + (size_t)c * LEAF * LEAF, a.lda, x);
                 trsm_store(X, a.lda, x);
-                continue;
+                if (c == W - 1) continue;
+            } else {
+                if (!have_inv) {                           // inv(L_cc) published by strip c's workgroup
+                    idx[0] = 2 + c;
+                    if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
+                    have_inv = true;
+                }
+                panel_product(s, 1.0, X, a.lda, a.inv + (size_t)c * LEAF * LEAF, (size_t)LEAF, 0.0, X, a.lda);
             }
-            if (!have_inv) {                           // inv(L_cc) published by strip c's workgroup
-                idx[0] = 2 + c;
-                if (!panel_wait(a.flags, idx, 1, a.dinfo, sh + 1, a.abort)) return false;
-                have_inv = true;
-            }
-            for (int t = 0; t <= W - 1 - c; ++t) {     // columns c+1..W-1 of this strip take the update
+            for (int t = 1; t <= W - 1 - c; ++t) {     // columns c+1..W-1 of this strip take the update
                 if (t == 1 && !have_rows) {            // ... which needs L(c',c) of the diagonal strips c' in (c, W)
                     int cnt = 0;
                     for (int cc = c + 1; cc < W; ++cc) idx[cnt++] = F0 + cc * PW_MAX + c;
                     if (cnt && !panel_wait(a.flags, idx, cnt, a.dinfo, sh + 1, a.abort)) return false;
                     have_rows = true;
                 }
-                const bool solve = t == 0;
-                const double *B = solve ? a.inv + (size_t)c * LEAF * LEAF : tileptr(c + t, c);
-                panel_product(s, solve ? 1.0 : -1.0, X, a.lda, B, solve ? (size_t)LEAF : a.lda, solve ? 0.0 : 1.0,
-                              solve ? X : tileptr(r, c + t), a.lda);
+                panel_product(s, -1.0, X, a.lda, tileptr(c + t, c), a.lda, 1.0, tileptr(r, c + t), a.lda);
             }
         }
     }
@@ -736,7 +846,7 @@ __global__ __launch_bounds__(LT) void panel_kernel(const PanelArgs a)
     __syncthreads();
     const int g = sh[0];
     __syncthreads();
-    if (g >= G) return;
+    if (g >= G + a.NH) return;
     (void)panel_strip(a, g, s, sh);
 }
 
@@ -760,6 +870,7 @@ struct PanelSeq {
     int *tver;
     int *abort;
     unsigned long long *census;
+    int helpers, tiles;     // the look-ahead driver's helper workgroups / tile-by-tile rows below (PanelArgs), from the surplus of the grid
 };
 
 __global__ __launch_bounds__(LT) void panel_seq_kernel(const PanelSeq q)
@@ -773,6 +884,12 @@ __global__ __launch_bounds__(LT) void panel_seq_kernel(const PanelSeq q)
         a.P = q.A + k0 + (size_t)k0 * q.lda; a.lda = q.lda;
         a.W = w / LEAF;
         a.R = a.G = (w + wnext) / LEAF;
+        a.below_early = q.tiles;
+        a.NH = (q.helpers && a.W > 2 && a.G + (a.W - 1) * (a.W - 2) / 2 <= (int)gridDim.x) ? (a.W - 1) * (a.W - 2) / 2 : 0;
+        if (q.tiles && wnext > 0 && a.W >= 2 && (int)gridDim.x - a.W - a.NH >= 1) {
+            a.tiles = 1;
+            a.G = a.W + min((int)gridDim.x - a.W - a.NH, (a.R - a.W) * a.W);
+        }
         a.inv = q.inv + (size_t)(k0 / LEAF) * LEAF * LEAF;
         a.dinfo = q.dinfo; a.goff = q.goff + k0;
         a.flags = q.flags + (size_t)(k0 / LEAF) * PFLAG_STRIDE;
@@ -781,7 +898,7 @@ __global__ __launch_bounds__(LT) void panel_seq_kernel(const PanelSeq q)
         a.tver = q.tver; a.tver_r0 = k0 / LEAF; a.tver_val = (k0 + w) / LEAF;
         a.abort = q.abort;
         a.census = (q.census && k < (int)cholq::TRACE_PANELS) ? q.census + 4 * cholq::TRACE_PANEL_WGS * (size_t)k : nullptr;
-        if (g < a.G && !panel_strip(a, g, s, sh)) return;
+        if (g < a.G + a.NH && !panel_strip(a, g, s, sh)) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -1200,7 +1317,16 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
     int band = 0;       // workgroups of the widest panel kernel: its diagonal strips + the rows of the next diagonal block
     for (size_t k = 0; k + 1 < starts.size(); ++k)
         band = std::max(band, (starts[k + 1] - starts[k] + (k + 2 < starts.size() ? starts[k + 2] - starts[k + 1] : 0)) / LEAF);
-    const int R = (band + 7) / 8;
+    // helper workgroups for the tiles inside the diagonal blocks and extra ones for the rows of the next diagonal block tile
+    // by tile (tunables "q_helpers", "q_tiles" = number of extra workgroups, 0 = strips as before)
+    static const int q_helpers = (int)tune("q_helpers", 0), q_tiles = (int)tune("q_tiles", 0);   // measured at n = 16384: 29.6 ms without, 30.1 - 30.8 with (8 workers fewer)
+    int nh_max = 0;
+    for (size_t k = 0; k + 1 < starts.size(); ++k) {
+        const int W = (starts[k + 1] - starts[k]) / LEAF;
+        if (q_helpers && W > 2) nh_max = std::max(nh_max, (W - 1) * (W - 2) / 2);
+    }
+    const int pgrid = band + nh_max + std::max(0, q_tiles);
+    const int R = (pgrid + 7) / 8;
     if (R > 4) return 1;
     hipStream_t sw = nullptr, sp = nullptr;
     if (queue_streams(qd, dev, R, &sw, &sp)) return 1;
@@ -1235,7 +1361,8 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         ps.inv = inv_blk; ps.dinfo = c.dinfo; ps.goff = off0; ps.flags = flags_blk;
         ps.ver = ws.ver; ps.ver_ld = tn; ps.tver = ws.tver; ps.abort = cholq::abort_word(ws);
         ps.census = cholq::trace_panel_base((int)(plan->tasks.size() / 2));
-        hipLaunchKernelGGL(panel_seq_kernel, dim3(band), dim3(LT), 0, sp, ps);
+        ps.helpers = q_helpers != 0; ps.tiles = q_tiles > 0;
+        hipLaunchKernelGGL(panel_seq_kernel, dim3(pgrid), dim3(LT), 0, sp, ps);
         SGPR_CHECK_LAUNCH();
         if ((rc = cholq::launch_workers(*plan, ws, A, lda, inv_blk, flags_blk, c.dinfo, PFLAG_STRIDE, sw))) return rc;
     }
@@ -1428,13 +1555,32 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
                 const int nwg = std::min((nbelow + per_wg - 1) / per_wg, PANEL_G_MAX - pa.W);
                 pa.G = pa.W + (nbelow > 0 ? std::max(1, nwg) : 0);
             }
+            // helpers for the tiles inside the diagonal block (tunable "panel_helpers", default on) and the early-hand-off
+            // solve for every column of the strips below ("panel_below_early")
+            static const bool helpers_on = tune("panel_helpers", 1) != 0, below_early_on = tune("panel_below_early", 1) != 0;
+            pa.NH = helpers_on && pa.W > 2 ? (pa.W - 1) * (pa.W - 2) / 2 : 0;
+            if (pa.G + pa.NH > PANEL_G_MAX) pa.NH = 0;
+            pa.below_early = below_early_on ? 1 : 0;
+            // one workgroup per tile of the rows below while they all fit the chip (the chain-bound sizes: a strip below is
+            // W solves + W (W - 1) / 2 products of 20 - 30 us on ONE CU, 265 us for W = 4 against the chain's 215)
+            static const bool tiles_on = tune("panel_tiles", 1) != 0;
+            static const double tile_mult = tune("panel_tile_mult", 1.0);   // 1 / 2 / 3: n = 8192 6.94 / 7.06 / 7.12 ms, 12288 16.1 / 16.5 / 16.6
+            if (tiles_on && !split && nbelow > 0 && pa.W >= 2 && nbelow < PFLAG_STRIDE) {
+                // workgroups for the tiles: all of them while the step waits for the chain anyway, else a multiple of the
+                // strips' number (every one holds a CU that the update beside loses)
+                const double chain_us = 60.0 * pa.W + 50.0;
+                int nt = u2_us < chain_us ? nbelow * pa.W : (int)(tile_mult * (pa.G - pa.W));
+                nt = std::max(1, std::min(std::min(nt, nbelow * pa.W), PANEL_G_MAX - pa.W - pa.NH));
+                pa.tiles = 1;
+                pa.G = pa.W + nt;
+            }
             const int t0 = (off0 + k0) / LEAF;
             pa.inv = cp.inv + (size_t)t0 * LEAF * LEAF;
             pa.dinfo = cp.dinfo; pa.goff = off0 + k0;
             pa.flags = c.flags + (size_t)t0 * PFLAG_STRIDE;
             pa.dbg = (PANEL_DBG && g_panel_dbg) ? g_panel_dbg + (size_t)16 * t0 : nullptr;
             // (at least W workgroups with an id that is a multiple of 8; surplus ones find no ticket and leave)
-            hipLaunchKernelGGL(panel_kernel, dim3(std::max(pa.G, 8 * (pa.W - 1) + 1)), dim3(LT), 0, sp, pa);
+            hipLaunchKernelGGL(panel_kernel, dim3(std::max(pa.G + pa.NH, 8 * (pa.W - 1) + 1)), dim3(LT), 0, sp, pa);
             SGPR_CHECK_LAUNCH();
             if (split) return trsm_rec(below, w, Akk, lda, Akk + w, lda, off0 + k0, cp);
             return 0;
@@ -1613,7 +1759,7 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
         (void)hipMemcpy(h.data(), g_panel_dbg, h.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(g_panel_dbg);
         g_panel_dbg = nullptr;
-        std::vector<double> d[6];
+        std::vector<double> d[9];
         for (int t = 1; t + 1 < T; ++t) {
             const unsigned long long *p = &h[16 * t], *q = &h[16 * (t + 1)];
             if (!p[0] || !p[5] || !q[0]) continue;               // first column of a panel: no chain stamps
@@ -1626,10 +1772,18 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
             d[3].back() = ((double)p[4] - (double)p[1]) * 0.01;   // solve stored -> leaf entered (the update)
             d[1].back() = (p[6] - p[0]) * 0.01;                   // E seen -> L staged
             d[2].back() = (p[7] - p[6]) * 0.01;                   // -> MFMA part done
+            d[6].push_back((p[11] - p[4]) * 0.01);                // leaf entered -> factor done
+            d[7].push_back((p[12] - p[11]) * 0.01);               // -> early flag set
+            d[8].push_back(((double)q[2] - (double)p[4]) * 0.01); // leaf entered -> next strip at its wait for E
+            if (getenv("SGPR_PANEL_DBG_ALL"))
+                fprintf(stderr, "  col %3d: leaf entry -> factor %.1f -> flag %.1f | next strip at wait %.1f, saw E %.1f | its solve %.1f, update %.1f\n", t,
+                        (p[11] - p[4]) * 0.01, (p[12] - p[4]) * 0.01, ((double)q[2] - (double)p[4]) * 0.01, ((double)q[0] - (double)p[4]) * 0.01,
+                        (q[1] - q[0]) * 0.01, ((double)q[4] - (double)q[1]) * 0.01);
         }
         auto med = [](std::vector<double> &x) { std::sort(x.begin(), x.end()); return x.empty() ? 0.0 : x[x.size() / 2]; };
         fprintf(stderr, "panel chain n=%d (%zu columns): E seen -> solve stored %.1f | E seen -> staged %.1f | -> MFMA part done %.1f | (solve stored -> leaf entry %.1f) | "
-                "leaf entry -> next E seen %.1f | whole leaf %.1f us\n", n, d[0].size(), med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]), med(d[5]));
+                "leaf entry -> next E seen %.1f (factor %.1f, -> flag set %.1f; next strip at its wait %.1f) | whole leaf %.1f us\n", n, d[0].size(), med(d[0]), med(d[1]), med(d[2]), med(d[3]), med(d[4]),
+                med(d[6]), med(d[7]), med(d[8]), med(d[5]));
     }
     return rc;
 }

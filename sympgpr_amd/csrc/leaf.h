@@ -36,7 +36,8 @@ __device__ __forceinline__ void store_wt(double *p, double v)
 //            X21 = -X22 L21 X11 for every pair of a level on the matrix cores.
 __device__ __forceinline__ void leaf_body(double *s /* LEAF_LDS doubles: the block, then two PW x (PW + 1) buffers */, int nb,
                                           double *A, size_t lda, double *inv, int *dinfo, int goff, int mode,
-                                          unsigned long long *stamps, int *early_flag = nullptr, bool preloaded = false)
+                                          unsigned long long *stamps, int *early_flag = nullptr, bool preloaded = false,
+                                          unsigned long long *rt = nullptr /* diagnostic: 100 MHz stamps (factor done, early flag set) */)
 {
     double *const sInv = s + LEAF * LLD;   // inv(L11) of the current panel and of the next one (double-buffered)
     const int tid = threadIdx.x;
@@ -246,6 +247,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF_LDS doubles: the blo
         put_panel(nend - PW, tid, LT, sInv + (((nend - PW) / PW) & 1) * PW * (PW + 1));
         __syncthreads();
         mark(4);
+        if (rt && tid == 0) rt[0] = __builtin_amdgcn_s_memrealtime();
     }
 
     // ---- inverse (LAPACK dtrtri order, last panel first); only the lower triangle of s is read.
@@ -291,6 +293,7 @@ __device__ __forceinline__ void leaf_body(double *s /* LEAF_LDS doubles: the blo
         __syncthreads();
         if (tid == 0)
             __hip_atomic_store((__attribute__((address_space(1))) int *)early_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rt && tid == 0) rt[1] = __builtin_amdgcn_s_memrealtime();
     }
     mark(5);
     // (I1) recursive doubling: with the diagonal blocks of size b inverted, the blocks of size 2b follow
