@@ -87,6 +87,35 @@ def cpu_baseline(family, n_pts_sample):
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count() or 1
+    # BASELINE.md 4's other two figures, on smaller samples so that the leg stays bounded: build_K on all cores (the C port of the
+    # same loops, oracle/sympgpr_oracle.c, OpenMP over columns -- the reference itself is single-threaded) and the factor /
+    # solve with ONE BLAS thread
+    variants = {}
+    try:
+        ncores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        Oracle().build_K(family, q, P, q, P, hyp, threads=ncores)
+        tb = time.perf_counter() - t0
+        variants["build_all_cores"] = {"kind": "port", "threads": ncores, "n": n, "seconds": tb, "gb_s": 8.0 * n * n / tb / 1e9}
+    except Exception as e:                       # the port is test infrastructure: its absence must not break the bench line
+        variants["build_all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        from threadpoolctl import threadpool_limits
+        n1 = min(n, 6144)
+        K1 = np.array(K[:n1, :n1], order="F")    # (K holds L now; any SPD matrix of that order times the same)
+        K1 = np.tril(K1) @ np.tril(K1).T + n1 * np.eye(n1)
+        with threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            L1 = scipy.linalg.cholesky(K1, lower=True, overwrite_a=True, check_finite=False)
+            tc1 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            scipy.linalg.solve_triangular(L1.T, scipy.linalg.solve_triangular(L1, z[:n1], lower=True, check_finite=False),
+                                          lower=False, check_finite=False)
+            ts1 = time.perf_counter() - t0
+        variants["factor_solve_1_blas_thread"] = {"n": n1, "cholesky_seconds": tc1, "cholesky_gflops": n1**3 / 3.0 / tc1 / 1e9,
+                                                  "two_solves_seconds": ts1}
+    except Exception as e:
+        variants["factor_solve_1_blas_thread"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return {
         "value": (n**3 / 3.0) / total / 1e12, "unit": "TFLOP/s", "cores": int(blas_threads),
         "kind": kind,
@@ -94,7 +123,7 @@ def cpu_baseline(family, n_pts_sample):
                   "%.1f GFLOP/s; 2x solve_triangular %.2fs" % (n, n_pts_sample, t_build, 8.0 * n * n / t_build / 1e9,
                                                                blas_threads, t_chol, n**3 / 3.0 / t_chol / 1e9, t_solve),
         "gram_gb_s": 8.0 * n * n / t_build / 1e9, "chol_tflops": n**3 / 3.0 / t_chol / 1e12,
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "variants": variants,
     }, alpha, (q, P, z, hyp, s2)
 
 
@@ -232,6 +261,8 @@ def main():
                     help="ORDER,COUNT: instead of the big fit, time COUNT independent nll_chol bodies of matrix order ORDER in one "
                          "batched call (sgpr_fit_batch: a CMA-ES generation / the Split_SympGPR sections) and print one JSON line "
                          "with fits/s, TFLOP/s and the roofline fraction, the reference's CPU path beside it")
+    ap.add_argument("--cond-iters", type=int, default=30,
+                    help="power / inverse iteration steps of the condition estimate printed beside the parity numbers (0 = skip)")
     ap.add_argument("--lower-only", action="store_true",
                     help="build only the lower triangle of K (what the factor reads) instead of the "
                          "full matrix build_K defines")
@@ -378,6 +409,8 @@ def main():
                "ms_device_part_of_host_buffer_calls": [float(v) for v in th],
                "column0_vs_alpha": float(np.linalg.norm(x0 - a) / np.linalg.norm(a)),
                "column0_vs_alpha_host_buffers": float(np.linalg.norm(Xs[:, 0] - a) / np.linalg.norm(a))}
+    # cond_2(Ky) of the full-size matrix, from below, with the device's own kernels (beside every parity number)
+    cond = fit.cond_estimate(args.cond_iters) if args.cond_iters > 0 else None
     # the Gram kernel alone, back to back (outside the timed region, not part of `value`): the build
     # inside a step starts on an idle chip right after the barrier and carries that warm-up
     rep = []
@@ -410,6 +443,7 @@ def main():
         "solve_gb_s": 8.0 * n * n / (stage[2] * 1e-3) / 1e9,
         "residual_Ky_alpha_minus_z": resid,
         "nll": nll,
+        "cond_estimate": cond,
     }
     traffic, traffic_source = load_traffic(n_pts, d, args.family, args.lower_only)
     alone_n, alone_flop, alone_ms = prof[0], prof[1], prof[2]
@@ -480,8 +514,27 @@ def main():
         cb, a_ref, (qs, Ps, zs, hs, s2s) = cpu_baseline(args.family if d == 1 else "A", args.cpu_sample)
         with SympFit(args.family if d == 1 else "A", qs, Ps, zs, hs, s2s) as fs:
             a_gpu = fs.run().alpha()
-        out["alpha_rel_err"] = float(np.linalg.norm(a_gpu - a_ref) / np.linalg.norm(a_ref))
-        out["alpha_rel_err_at"] = "n=%d vs the CPU baseline's solve" % (2 * args.cpu_sample)
+            cond_s = fs.cond_estimate(args.cond_iters) if args.cond_iters > 0 else None
+        err1 = float(np.linalg.norm(a_gpu - a_ref) / np.linalg.norm(a_ref))
+        if d == 1:
+            out["alpha_rel_err"] = err1
+            out["alpha_rel_err_at"] = "n=%d, family %s, vs the CPU baseline's solve" % (2 * args.cpu_sample, args.family)
+            out["alpha_rel_err_cond_estimate"] = cond_s
+        else:
+            # the configuration's OWN kernel: a sample of the same family and d against the oracle's fit (oracle.fit_nd: restated
+            # kernels + SciPy's cholesky / solve_triangular); the d = 1 family-A figure of the CPU baseline's sample beside it
+            from oracle.oracle import Oracle
+            ns = max(64, min(n_pts, 12288 // (2 * d)))
+            Xs, zs2, hs2, s2s2 = synth_pairs(ns, d)
+            a_o, _, _ = Oracle().fit_nd(args.family, Xs, zs2, hs2, s2s2)
+            with SympFit.pairs(args.family, Xs, zs2, hs2, s2s2) as fs:
+                a_g = fs.run().alpha()
+                cond_s2 = fs.cond_estimate(args.cond_iters) if args.cond_iters > 0 else None
+            out["alpha_rel_err"] = float(np.linalg.norm(a_g - a_o) / np.linalg.norm(a_o))
+            out["alpha_rel_err_at"] = "n=%d (N=%d points, %d canonical pairs each), family %s, vs oracle.fit_nd" % (2 * d * ns, ns, d, args.family)
+            out["alpha_rel_err_cond_estimate"] = cond_s2
+            out["alpha_rel_err_d1_family_A"] = err1
+            out["alpha_rel_err_d1_family_A_at"] = "n=%d vs the CPU baseline's solve" % (2 * args.cpu_sample)
         out["cpu_baseline"] = cb
         # the checker's second job: rows of Ky at full size re-evaluated on the host by the oracle
         # (restated Fortran formulas), so the full-size residual does not rest on any device formula

@@ -34,9 +34,10 @@
 extern "C" {
 #endif
 
-#define SGPR_ABI_VERSION 4   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
+#define SGPR_ABI_VERSION 5   /* 2: solves take a writable workspace, sgpr_solve_status_dev, 12 / 7-double profile records, probes in their own library;
                                 3: sgpr_fit_solve_rhs_ms, sgpr_potrf_info_dev, sgpr_trim (entry points added, none changed);
-                                4: sgpr_fit_solve_rhs_dev (added) */
+                                4: sgpr_fit_solve_rhs_dev (added);
+                                5: sgpr_fit_cond_estimate, sgpr_fit_trim, sgpr_gemm_nn_dev, sgpr_trsm_rl_dev, sgpr_copy_blocks_dev (added) */
 
 enum { SGPR_FAM_A = 0,   /* periodic(q) x SE(P), product : 05_tokamak/SympGPR/kernels.f90      */
        SGPR_FAM_B = 1,   /* periodic(q) + SE(P), sum     : 01_pendulum/explicit/kernels_sum.f90 */
@@ -186,11 +187,20 @@ int sgpr_fit_nll_grad_terms(sgpr_fit_t f, double *terms5);
 int sgpr_fit_eig(sgpr_fit_t f, double *w, double *c);
 /* K* . alpha for m test points with d pairs each: Xt (m x 2d), out (m x 2d), both column-major */
 int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, double *out);
+/* cond_2(Ky) estimated from below with the device's own kernels (needs a valid factor): lambda_max by `iters` power iterations on
+ * Ky v -- the rows of K re-evaluated from the training points by the prediction kernel, plus |sig2n| v --, lambda_min by `iters`
+ * inverse iterations with the cached factor.  out4 = {lambda_max, lambda_min, cond, relative change of the quotients in the last
+ * step}.  The reference never computes it; SURVEY.md 7 / 8(d) ask for it beside every parity number (the tolerance on alpha is a
+ * multiple of cond * eps).  ABI 5. */
+int sgpr_fit_cond_estimate(sgpr_fit_t f, int iters, double *out4);
 /* milliseconds of the last build / factor / solve stage (hipEvent timing on the fit's stream) */
 int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms);
 /* milliseconds of the device part of the last sgpr_fit_solve_rhs / _dev (the two triangular solves with their pack / unpack passes;
  * the host <-> device copies of B are outside): -1 when there has been none */
 int sgpr_fit_solve_rhs_ms(sgpr_fit_t f, double *ms);
+/* gives back the device scratch the block solves of this fit keep from call to call (sgpr_fit_solve_rhs / _dev: ~0.8 GB at
+ * n = 98 304); the next block solve allocates it again.  Waits for the fit's stream.  ABI 5. */
+int sgpr_fit_trim(sgpr_fit_t f);
 /* device pointers of the fit (for callers that own a torch / HIP context): K/L, alpha */
 int sgpr_fit_device_ptrs(sgpr_fit_t f, void **dA, size_t *lda, void **dalpha);
 int sgpr_fit_destroy(sgpr_fit_t f);
@@ -290,6 +300,16 @@ int sgpr_trsv_dev(int n, const double *L, size_t ldl, void *work, double *b, int
  * workgroups (a bounded wait ran out: a device problem, never a property of the matrix).  Call it after the last
  * sgpr_trsv_dev / sgpr_potrs_vec_dev of a solve before trusting b. */
 int sgpr_solve_status_dev(int n, const double *L, size_t ldl, const void *work, void *stream);
+/* C (m x n) := beta C + alpha A (m x k) B (k x n)   (ABI 5; the backward half of a block of right-hand sides stored as rows) */
+int sgpr_gemm_nn_dev(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
+                     double beta, double *C, size_t ldc, void *stream);
+/* B (m x n) := B L^-1 with L (n x n) lower and `work` as left by sgpr_potrf_dev on it: with the right-hand sides of L^T X = Y stored
+ * as the ROWS of B this is the backward solve (sgpr_trsm_rlt_dev, B := B L^-T, is the forward one).  ABI 5. */
+int sgpr_trsm_rl_dev(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work, void *stream);
+/* cnt blocks of rows x cols doubles: block i is copied from src + i * sstep (leading dimension lds) to dst + i * dstep (ldd).
+ * The packing / regrouping copies of a block-cyclic panel exchange as one launch on the caller's stream.  ABI 5. */
+int sgpr_copy_blocks_dev(int rows, int cols, int cnt, const double *src, size_t lds, size_t sstep, double *dst, size_t ldd,
+                         size_t dstep, void *stream);
 /* y -= A x (trans = 0: A m x k, x k, y m) or y -= A^T x (trans != 0: x m, y k) */
 int sgpr_gemv_sub_dev(int trans, int m, int k, const double *A, size_t lda, const double *x,
                       double *y, void *stream);

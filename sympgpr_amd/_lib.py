@@ -13,7 +13,7 @@ FIT_LOWER_ONLY, FIT_REG, FIT_BLOCK_QQ, FIT_BLOCK_PP = 1, 4, 8, 16
 MAP_WRAP_Q, MAP_WRAP_P, MAP_EXPLICIT = 1, 2, 4
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
-ABI_VERSION = 4      # include/sympgpr_hip.h: SGPR_ABI_VERSION
+ABI_VERSION = 5      # include/sympgpr_hip.h: SGPR_ABI_VERSION
 _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
@@ -71,6 +71,8 @@ SIGNATURES = {
     "sgpr_fit_inverse": (C.c_int, [_vp, _dp, C.c_size_t]),
     "sgpr_fit_predict_nd": (C.c_int, [_vp, C.c_int, _dp, C.c_size_t, _dp]),
     "sgpr_fit_stage_ms": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "sgpr_fit_cond_estimate": (C.c_int, [_vp, C.c_int, _dp]),
+    "sgpr_fit_trim": (C.c_int, [_vp]),
     "sgpr_fit_solve_rhs_ms": (C.c_int, [_vp, _dp]),
     "sgpr_potrf_info_dev": (C.c_int, [C.c_int, _vp]),
     "sgpr_trim": (C.c_int, []),
@@ -99,6 +101,10 @@ SIGNATURES = {
                                       C.c_double, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "sgpr_trsv_dev": (C.c_int, [C.c_int, _vp, C.c_size_t, _vp, _vp, C.c_int, _vp]),
     "sgpr_gemv_sub_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "sgpr_gemm_nn_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_size_t, _vp, C.c_size_t, C.c_double, _vp,
+                                   C.c_size_t, _vp]),
+    "sgpr_trsm_rl_dev": (C.c_int, [C.c_int, C.c_int, _vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp]),
+    "sgpr_copy_blocks_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp]),
     "sgpr_predict_rows_dev": (C.c_int, [C.c_int, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _dp, C.c_int, _vp, _vp, _vp,
                                         _vp]),
     "sgpr_predict_nd_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, _dp, C.c_int,

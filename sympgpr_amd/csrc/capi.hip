@@ -878,6 +878,97 @@ int sgpr_fit_predict_nd(sgpr_fit_t f, int m, const double *Xt, size_t ldxt, doub
     return 0;
 }
 
+// cond_2(Ky) from below: lambda_max by power iteration on Ky v (the rows of K are re-evaluated from the training points by the
+// prediction kernel -- the matrix itself has been overwritten by its factor -- plus |sig2n| v), lambda_min by inverse iteration
+// with the cached factor (two strip solves per step).  Both are Rayleigh quotients of unit vectors, so lambda_max is a lower
+// and lambda_min an upper bound: the estimate never exceeds the true condition number.  Vector arithmetic on the host (n
+// doubles per step); out4 = {lambda_max, lambda_min, cond, relative change of the two quotients in their last step (the larger)}.
+// "report cond (or a Lanczos estimate) next to every parity number".
+int sgpr_fit_cond_estimate(sgpr_fit_t f, int iters, double *out4)
+{
+    if (!f || !out4 || iters < 1) { set_error("fit_cond_estimate: bad arguments"); return SGPR_E_ARG; }
+    if (!f->factored) { set_error("fit_cond_estimate: no valid factor"); return SGPR_E_STATE; }
+    if (f->flags & (SGPR_FIT_BLOCK_QQ | SGPR_FIT_BLOCK_PP)) { set_error("fit_cond_estimate: not defined for a single-block fit"); return SGPR_E_STATE; }
+    const size_t n = (size_t)f->n;
+    const int m = f->npts;
+    DevBuf dv, dw;
+    int rc;
+    if ((rc = dv.alloc(n * sizeof(double))) || (rc = dw.alloc(n * sizeof(double)))) return rc;
+    std::vector<double> v(n), w(n);
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    double nrm = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        v[i] = (double)(lcg >> 11) / 9007199254740992.0 - 0.5;
+        nrm += v[i] * v[i];
+    }
+    nrm = std::sqrt(nrm);
+    for (size_t i = 0; i < n; ++i) v[i] /= nrm;
+    const std::vector<double> v0 = v;
+    double hyp1[4] = {f->kc.lx, f->kc.ly, f->kc.sig, 0.0};
+    int nh1 = 3;
+    if (family_has_p(f->family)) { hyp1[2] = f->kc.p; hyp1[3] = f->kc.sig; nh1 = 4; }
+    auto normalise = [&](const std::vector<double> &src, std::vector<double> &dst, double &quot) {
+        double dot = 0.0, nn = 0.0;
+        for (size_t i = 0; i < n; ++i) { dot += dst[i] * src[i]; nn += src[i] * src[i]; }
+        quot = dot;                                     // v^T (M v), |v| = 1
+        nn = std::sqrt(nn);
+        for (size_t i = 0; i < n; ++i) dst[i] = src[i] / nn;
+    };
+    double lmax = 0.0, lmin_inv = 0.0, ch_max = 1.0, ch_min = 1.0;
+    for (int it = 0; it < iters; ++it) {                // ---- lambda_max
+        SGPR_HIP(hipMemcpyAsync(dv.p, v.data(), n * sizeof(double), hipMemcpyHostToDevice, f->st));
+        if (f->flags & SGPR_FIT_REG) {
+            rc = predict_reg(f->family, m, f->dx, f->dy, m, f->dx, f->dy, f->kc, dv.as<double>(), dw.as<double>(), f->st);
+        } else if (f->d > 1) {
+            rc = predict_nd(f->family, f->d, m, f->dX, (size_t)m, m, f->dX, (size_t)m, f->hyp_nd, f->nhyp_nd, dv.as<double>(),
+                            dw.as<double>(), f->st);
+        } else {
+            rc = predict_rows(f->family, m, f->dx, f->dy, m, f->dx, f->dy, f->kc, dv.as<double>(), dw.as<double>(),
+                              dw.as<double>() + m, f->st);
+        }
+        if (rc) return rc;
+        SGPR_HIP(hipMemcpyAsync(w.data(), dw.p, n * sizeof(double), hipMemcpyDeviceToHost, f->st));
+        SGPR_HIP(hipStreamSynchronize(f->st));
+        const double s2 = std::fabs(f->sig2n);
+        for (size_t i = 0; i < n; ++i) w[i] += s2 * v[i];
+        double q;
+        normalise(w, v, q);
+        ch_max = lmax > 0.0 ? std::fabs(q - lmax) / q : 1.0;
+        lmax = q;
+    }
+    v = v0;
+    for (int it = 0; it < iters; ++it) {                // ---- 1 / lambda_min
+        SGPR_HIP(hipMemcpyAsync(dw.p, v.data(), n * sizeof(double), hipMemcpyHostToDevice, f->st));
+        if ((rc = potrs_vec(f->n, f->dA, n, f->work, dw.as<double>(), f->st))) return rc;
+        if ((rc = solve_status(f->n, f->dA, n, f->work, f->st))) return rc;
+        SGPR_HIP(hipMemcpyAsync(w.data(), dw.p, n * sizeof(double), hipMemcpyDeviceToHost, f->st));
+        SGPR_HIP(hipStreamSynchronize(f->st));
+        double q;
+        normalise(w, v, q);
+        ch_min = lmin_inv > 0.0 ? std::fabs(q - lmin_inv) / q : 1.0;
+        lmin_inv = q;
+    }
+    (void)hyp1; (void)nh1;
+    out4[0] = lmax;
+    out4[1] = lmin_inv > 0.0 ? 1.0 / lmin_inv : 0.0;
+    out4[2] = lmax * lmin_inv;
+    out4[3] = ch_max > ch_min ? ch_max : ch_min;
+    return 0;
+}
+
+int sgpr_fit_trim(sgpr_fit_t f)
+{
+    if (!f) { set_error("null fit"); return SGPR_E_ARG; }
+    if (f->rhs_scratch) {
+        SGPR_HIP(hipStreamSynchronize(f->st));
+        (void)hipFree(f->rhs_scratch);
+        f->rhs_scratch = nullptr;
+        f->rhs_scratch_bytes = 0;
+    }
+    return 0;
+}
+
 int sgpr_fit_stage_ms(sgpr_fit_t f, double *build_ms, double *factor_ms, double *solve_ms)
 {
     if (!f) { set_error("null fit"); return SGPR_E_ARG; }
@@ -1037,6 +1128,51 @@ int sgpr_gemv_sub_dev(int trans, int m, int k, const double *A, size_t lda, cons
     if (m < 0 || k < 0 || (m > 0 && lda < (size_t)m)) { set_error("gemv: bad shape"); return SGPR_E_ARG; }
     return trans ? gemv_t_sub(m, k, A, lda, x, y, static_cast<hipStream_t>(stream))
                  : gemv_n_sub(m, k, A, lda, x, y, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_gemm_nn_dev(int m, int n, int k, double alpha, const double *A, size_t lda, const double *B, size_t ldb,
+                     double beta, double *C, size_t ldc, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return gemm_nn(m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, static_cast<hipStream_t>(stream));
+}
+
+int sgpr_trsm_rl_dev(int m, int n, const double *L, size_t ldl, double *B, size_t ldb, const void *work, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    return trsm_rl(m, n, L, ldl, B, ldb, work, static_cast<hipStream_t>(stream));
+}
+
+namespace sgpr { namespace {
+// cnt blocks of rows x cols doubles, block i from src + i * sstep (leading dimension lds) to dst + i * dstep (ldd): the panel
+// packing / regrouping copies of the block-cyclic driver in one launch (rows fastest: 512-byte runs per wave)
+__global__ __launch_bounds__(256) void copy_blocks_kernel(int rows, int cols, int cnt, const double *src, size_t lds, size_t sstep,
+                                                          double *dst, size_t ldd, size_t dstep)
+{
+    const int i = blockIdx.z;
+    const double *s = src + (size_t)i * sstep;
+    double *d = dst + (size_t)i * dstep;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    for (int c = blockIdx.y; c < cols; c += gridDim.y) d[(size_t)r + (size_t)c * ldd] = s[(size_t)r + (size_t)c * lds];
+}
+} }
+
+int sgpr_copy_blocks_dev(int rows, int cols, int cnt, const double *src, size_t lds, size_t sstep, double *dst, size_t ldd,
+                         size_t dstep, void *stream)
+{
+    int rc = need_device();
+    if (rc) return rc;
+    if (rows < 0 || cols < 0 || cnt < 0 || (rows > 0 && (lds < (size_t)rows || ldd < (size_t)rows))) { set_error("copy_blocks: bad shape"); return SGPR_E_ARG; }
+    if (rows == 0 || cols == 0 || cnt == 0) return 0;
+    if (cnt > 65535) { set_error("copy_blocks: more than 65535 blocks"); return SGPR_E_ARG; }
+    const dim3 grid((unsigned)((rows + 255) / 256), (unsigned)std::min(cols, 1024), (unsigned)cnt);
+    hipLaunchKernelGGL(sgpr::copy_blocks_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), rows, cols, cnt, src, lds, sstep,
+                       dst, ldd, dstep);
+    SGPR_CHECK_LAUNCH();
+    return 0;
 }
 
 int sgpr_predict_rows_dev(int family, int m, const double *q, const double *P, int n0, const double *xtrain,

@@ -560,14 +560,25 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
     // (~50 us per tile, the whole fixed cost of a short-k launch: k = 512 ran at 42 TFLOP/s).
     const double alpha = g.alpha, beta = g.beta;
     double *const cbase = g.C + (size_t)(row0 + wm * 64 + l15) + (size_t)(col0 + wn * 64 + l4) * g.ldc;
+    // ... and the fetch of the NEXT sixteen goes out before the current sixteen are stored.  (Round 5: the ~15 us a tile spends
+    // outside its k-loop are bandwidth, not latency -- all 256 workgroups of a wave of tiles reach their epilogue together,
+    // 134 MB of C at 8 TB/s; the pipelined fetch gains 0.8 us of them: profiles/r05/gemm_k_epilogue.txt.)
+    double old[2][4][4];
+    auto fetch = [&](int i, double (&o)[4][4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[r][j] = cbase[(size_t)(j * 16) + (size_t)(i * 16 + 4 * r) * g.ldc];
+    };
+    if (beta != 0.0) fetch(0, old[0]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        double old[4][4];
+        if (beta != 0.0 && i + 1 < 4) fetch(i + 1, old[(i + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // the sixteen of this round have landed, the next sixteen may still be in flight (loads return in order)
         if (beta != 0.0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) old[r][j] = cbase[(size_t)(j * 16) + (size_t)(i * 16 + 4 * r) * g.ldc];
+            if (i + 1 < 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -575,7 +586,7 @@ __device__ __forceinline__ void gemm_body_dma(const GemmArgs &g, double *smem, i
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double v = alpha * acc[i][j][r];
-                cbase[(size_t)(j * 16) + (size_t)(i * 16 + 4 * r) * g.ldc] = (beta == 0.0) ? v : __builtin_fma(beta, old[r][j], v);
+                cbase[(size_t)(j * 16) + (size_t)(i * 16 + 4 * r) * g.ldc] = (beta == 0.0) ? v : __builtin_fma(beta, old[i & 1][r][j], v);
             }
         __builtin_amdgcn_sched_barrier(0);
     }

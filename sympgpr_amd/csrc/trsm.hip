@@ -886,6 +886,14 @@ void trsm_piece_of(int u, int C, int T, int out[5])
 }
 void trsm_piece_counts(int T, int C, size_t out[2]) { out[0] = piece_tickets(T, C); out[1] = piece_partials(T, C); }
 
+// every hand-off word of a forward + backward pair back to zero EXCEPT the two give-up words
+static __global__ void state_reset_kernel(int *state, int force_giveup)
+{
+    const int i = threadIdx.x;
+    if (i < TRSM_STATE_INTS && i != 2 && i != 6) state[i] = 0;
+    if (force_giveup && i == 2) state[2] = 1;
+}
+
 bool trsm_strips_ok(int n, const double *L, size_t ldl)
 {
     static const bool off = [] { const char *e = getenv("SGPR_TRSM"); return e && e[0] == 'r'; }();
@@ -930,11 +938,18 @@ int potrs_strips(int n, const double *L, size_t ldl, const double *inv, double *
     double *I0 = scratch, *I1 = scratch + img, *S = scratch + 2 * img, *M = scratch + 3 * img, *X = M + (size_t)T * MSLOTS * MFRAG;
     const size_t xbytes = piece_partials(T, piece) * XPART * sizeof(double);
     int *mflag = reinterpret_cast<int *>(X + piece_partials(T, piece) * XPART);     // T + 1 ints per triangular solve
+    // The give-up words (state[2], state[6]) are cleared ONCE per call: a pass that gave up stays on record while the later
+    // 64-column passes reset their tickets and ready words only (and leave at their first look at it), so the status the
+    // caller reads after the last pass covers every pass.  Tunable "trsm_force_giveup_pass" (tests, through the probe
+    // library): raise the forward give-up word in front of that pass.
+    SGPR_HIP(hipMemsetAsync(state, 0, TRSM_STATE_INTS * sizeof(int), st));
+    const int force_pass = (int)tune("trsm_force_giveup_pass", -1);
     for (int c0 = 0; c0 < nrhs; c0 += MS_NC) {
         const int nc = nrhs - c0 < MS_NC ? nrhs - c0 : MS_NC;
         hipLaunchKernelGGL(pack_rhs_kernel, dim3((n + 63) / 64), dim3(256), 0, st, n, nc, B + (size_t)c0 * ldb, ldb, I0);
         SGPR_CHECK_LAUNCH();
-        SGPR_HIP(hipMemsetAsync(state, 0, TRSM_STATE_INTS * sizeof(int), st));
+        hipLaunchKernelGGL(state_reset_kernel, dim3(1), dim3(64), 0, st, state, force_pass == c0 / MS_NC ? 1 : 0);
+        SGPR_CHECK_LAUNCH();
         SGPR_HIP(hipMemsetAsync(I1, 0xFF, 2 * img * sizeof(double), st));       // P and S of the forward solve
         if (xbytes) SGPR_HIP(hipMemsetAsync(X, 0xFF, xbytes, st));
         SGPR_HIP(hipMemsetAsync(mflag, 0, (size_t)2 * (T + 1) * sizeof(int), st));

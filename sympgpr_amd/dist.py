@@ -25,6 +25,11 @@ one nb-vector reduce + one broadcast per block step.
 This mirrors, for N beyond one GPU's HBM, the body of nll_chol (python/functions/func.py:189-196
 of the reference), which has no parallel form of its own.
 
+Storage is PACKED LOWER by blocks (round 5): of its local column block J a rank keeps only the row blocks I >= J, as one
+column-major panel of its own leading dimension -- half the bytes of the dense local piece, which is what puts the
+n = 262 144 configuration on two GPUs (137 GB of matrix per rank instead of 275) -- and the Gram build evaluates only
+those blocks.  The factor never reads anything else.
+
 The numerical work is delegated to an `ops` object: `HipOps` (below) binds the C ABI on torch
 CUDA tensors and is the only product backend; tests/ supply a NumPy backend to exercise the
 distribution logic under gloo without a GPU.
@@ -53,20 +58,23 @@ def _count_le(K, p, nproc):
 
 
 def hbm_plan(N, d, nb, world, rank=0):
-    """Bytes of HBM rank `rank` of `world` needs for N points, d pairs per point, block size nb: the local piece of Ky, the
-    two sets of panel operand buffers, the diagonal block + factor workspace, the replicated vectors.  Pure arithmetic
-    (the same bookkeeping as DistFit.__init__ / _buffers), so that a run can be refused BEFORE anything is allocated."""
+    """Bytes of HBM rank `rank` of `world` needs for N points, d pairs per point, block size nb: the local piece of Ky (packed
+    lower: of column block J the row blocks I >= J), the two sets of panel operand buffers, the diagonal block + factor
+    workspace + the store of the owned diagonal blocks' workspaces, the replicated vectors.  Pure arithmetic (the same
+    bookkeeping as DistFit.__init__ / _buffers), so that a run can be refused BEFORE anything is allocated."""
     pr, pc = grid_shape(world)
     pi, pj = rank % pr, rank // pr
     n = 2 * d * N
     nbk = n // nb
-    rows, cols = len(range(pi, nbk, pr)), len(range(pj, nbk, pc))
-    per_q = [len([J for J in range(pj, nbk, pc) if J % pr == q]) for q in range(pr)]
-    blocks = 2 * (max(rows, 1) + max(cols, 1) + sum(max(c, 1) for c in per_q))
+    rows, cols = list(range(pi, nbk, pr)), list(range(pj, nbk, pc))
+    per_q = [len([J for J in cols if J % pr == q]) for q in range(pr)]
+    blocks = 2 * (max(len(rows), 1) + max(len(cols), 1) + sum(max(c, 1) for c in per_q))
     leaves = (nb + 127) // 128
     work = leaves * 128 * 128 * 8 + 4 * leaves * 296 + 2 * nb * 8 + (2 << 20)      # inverses, hand-off words, solve vectors, slack
-    out = {"matrix": 8 * rows * nb * cols * nb, "panel_buffers": 8 * blocks * nb * nb,
-           "diag_block_and_workspace": 8 * nb * nb + 2 * work, "vectors": 8 * 6 * n}
+    owned_diag = len([K for K in range(nbk) if K % pr == pi and K % pc == pj])
+    packed = sum(len(rows) - _count_le(J - 1, pi, pr) for J in cols)
+    out = {"matrix": 8 * packed * nb * nb, "panel_buffers": 8 * blocks * nb * nb,
+           "diag_block_and_workspace": 8 * nb * nb + (2 + owned_diag) * work, "vectors": 8 * 6 * n}
     out["total"] = sum(out.values())
     return out
 
@@ -138,10 +146,26 @@ class HipOps:
         L.check(self.lib.sgpr_trsm_rlt_dev(m, nb, self._p(Lkk), nb, self._p(B, boff), ldb, self._p(work),
                                            self.stream()), "sgpr_trsm_rlt_dev")
 
-    def syrk_update(self, m, n, k, A, lda, B, ldb, Cm, coff, ldc, blk, pr, pi, pc, pj):
-        L.check(self.lib.sgpr_gemm_nt_bc_dev(m, n, k, -1.0, self._p(A), lda, self._p(B), ldb, 1.0,
-                                             self._p(Cm, coff), ldc, blk, pr, pi, pc, pj, self.stream()),
-                "sgpr_gemm_nt_bc_dev")
+    def gemm_nt(self, m, n, k, alpha, A, aoff, lda, B, boff, ldb, beta, Cm, coff, ldc):
+        """C (m x n) := beta C + alpha A (m x k) B (n x k)^T on the fp64 MFMA kernel"""
+        L.check(self.lib.sgpr_gemm_nt_dev(m, n, k, alpha, self._p(A, aoff), lda, self._p(B, boff), ldb, beta,
+                                          self._p(Cm, coff), ldc, 0, 0, self.stream()), "sgpr_gemm_nt_dev")
+
+    def gemm_nn(self, m, n, k, alpha, A, aoff, lda, B, boff, ldb, beta, Cm, coff, ldc):
+        """C (m x n) := beta C + alpha A (m x k) B (k x n)"""
+        L.check(self.lib.sgpr_gemm_nn_dev(m, n, k, alpha, self._p(A, aoff), lda, self._p(B, boff), ldb, beta,
+                                          self._p(Cm, coff), ldc, self.stream()), "sgpr_gemm_nn_dev")
+
+    def trsm_rows(self, m, nb, Lkk, work, B, boff, ldb, trans):
+        """right-hand sides as the m ROWS of B (m x nb): B := B L^-T (trans = 0: L X = B^T) or B L^-1 (trans = 1: L^T X = B^T)"""
+        fn = self.lib.sgpr_trsm_rl_dev if trans else self.lib.sgpr_trsm_rlt_dev
+        L.check(fn(m, nb, self._p(Lkk), nb, self._p(B, boff), ldb, self._p(work), self.stream()), "sgpr_trsm_rl(t)_dev")
+
+    def copy_blocks(self, rows, cols, cnt, src, soff, lds, sstep, dst, doff, ldd, dstep):
+        """cnt blocks of rows x cols doubles, block i from src + soff + i * sstep (ld lds) to dst + doff + i * dstep (ld ldd):
+        the pack / regroup copies of the panel exchange as ONE launch on the current stream"""
+        L.check(self.lib.sgpr_copy_blocks_dev(rows, cols, cnt, self._p(src, soff), lds, sstep, self._p(dst, doff), ldd, dstep,
+                                              self.stream()), "sgpr_copy_blocks_dev")
 
     def trsv(self, nb, Lkk, work, b, trans):
         L.check(self.lib.sgpr_trsv_dev(nb, self._p(Lkk), nb, self._p(work), self._p(b), trans, self.stream()),
@@ -202,34 +226,49 @@ class DistFit:
         self.nb = self._pick_nb(self.N, nb, 1)
         nb = self.nb
         self.nbk = self.n // nb
-        nbN = self.N // nb
         self.hyp = np.asarray(hyp, dtype=np.float64)
         self.sig2n = abs(float(sig2n))
         self.rows = list(range(self.pi, self.nbk, self.pr))   # global block rows held here
         self.cols = list(range(self.pj, self.nbk, self.pc))
-        self.mloc, self.nloc = len(self.rows) * nb, len(self.cols) * nb
+        self.mloc = len(self.rows) * nb
+        # packed lower storage: of local column block lj (global J) the local row blocks li >= lifirst[lj] (global I >= J),
+        # one column-major panel of leading dimension ld[lj] at element offset coloff[lj]
+        self.lifirst = [_count_le(J - 1, self.pi, self.pr) for J in self.cols]
+        self.ld = [(len(self.rows) - f) * nb for f in self.lifirst]
+        self.coloff = [0]
+        for v in self.ld:
+            self.coloff.append(self.coloff[-1] + v * nb)
         self.x = np.asarray(x, dtype=np.float64)
         self.y = np.asarray(y, dtype=np.float64)
         # HBM plan of this rank against what the device has free, BEFORE the first allocation (a rank that dies in hipMalloc
-        # half way through leaves the others in a collective)
+        # half way through leaves the others in a collective) -- and the verdict is SHARED before anybody raises: free memory
+        # differs from device to device, and one rank raising alone would leave the others in the first broadcast of factor()
         self.plan = hbm_plan(self.N, self.d, nb, self.world, self.rank)
+        assert self.plan["matrix"] == 8 * self.coloff[-1]
         if hasattr(ops, "mem_free"):
             free = ops.mem_free()
-            if self.plan["total"] > free:
-                raise MemoryError("rank %d of %d: n = %d in %d x %d blocks on a %d x %d grid needs %.1f GB of HBM here (%s), %.1f GB are free"
+            short = torch.tensor([max(0.0, float(self.plan["total"] - free))], dtype=torch.float64, device=ops.device)
+            if self.world > 1:
+                dist.all_reduce(short, op=dist.ReduceOp.MAX, group=group)
+            if float(short.item()) > 0:
+                raise MemoryError("rank %d of %d: n = %d in %d x %d blocks on a %d x %d grid needs %.1f GB of HBM here (%s), %.1f GB are "
+                                  "free; the rank that is shortest is short of %.1f GB (every rank raises)"
                                   % (self.rank, self.world, self.n, nb, nb, self.pr, self.pc, self.plan["total"] / 1e9,
-                                     ", ".join("%s %.1f" % (k, v / 1e9) for k, v in self.plan.items() if k != "total"), free / 1e9))
+                                     ", ".join("%s %.1f" % (k, v / 1e9) for k, v in self.plan.items() if k != "total"), free / 1e9,
+                                     float(short.item()) / 1e9))
         self.z = torch.as_tensor(np.asarray(z, dtype=np.float64)).to(ops.device)
-        # local matrix, column-major (mloc x nloc), as a flat tensor
-        self.A = ops.empty(self.mloc * self.nloc)
-        self.A2 = self.A.view(self.nloc, self.mloc)            # [local col, local row]
+        self.A = ops.empty(max(self.coloff[-1], 1))             # the packed local matrix, flat
         # L_KK and the factor workspace back to back: [L_KK | leaf inverses | scratch] -- the diagonal block and the
         # inverses of its leaves travel down the process column as ONE message (the first nb^2 + inv doubles)
-        self.inv_size = ops.inv_size(nb) if hasattr(ops, "inv_size") else ops.work_size(nb)
-        self._kkbuf = ops.empty(nb * nb + ops.work_size(nb))
+        self.wsize = ops.work_size(nb)
+        self.inv_size = ops.inv_size(nb) if hasattr(ops, "inv_size") else self.wsize
+        self._kkbuf = ops.empty(nb * nb + self.wsize)
         self.Lkk = self._kkbuf[:nb * nb]
         self.wbuf = self._kkbuf[nb * nb:]
-        self.work = {}                                         # K -> leaf inverses of L_KK (owner only)
+        # the workspaces of the diagonal blocks this rank owns (leaf inverses + the solves' hand-off words), one persistent store
+        self.owned = [K for K in range(self.nbk) if K % self.pr == self.pi and K % self.pc == self.pj]
+        self._wstore = ops.empty(max(len(self.owned), 1) * self.wsize)
+        self.work = {K: self._wstore[s * self.wsize:(s + 1) * self.wsize] for s, K in enumerate(self.owned)}
         self.info_t = ops.zeros(2, dtype=torch.int32)
         # process-column / process-row groups (every rank creates all of them, same order)
         self.col_groups = [dist.new_group([q + c * self.pr for q in range(self.pr)]) for c in range(self.pc)]
@@ -250,13 +289,23 @@ class DistFit:
     def grank(self, pi, pj):
         return pi + pj * self.pr
 
+    # ---- the packed layout
+    def _off(self, li, lj):
+        """element offset of local block (li, lj); li >= lifirst[lj]"""
+        return self.coloff[lj] + (li - self.lifirst[lj]) * self.nb
+
+    def _blk(self, li, lj):
+        """local block (li, lj) as a [column, row] view"""
+        nb = self.nb
+        return self.A.as_strided((nb, nb), (self.ld[lj], 1), self._off(li, lj))
+
     def describe(self, steps=2):
         """What this rank will do, as data: its communicators and, for the first `steps` panel steps, the collectives it
         issues in issue order -- (step K, communicator, root (global rank), doubles, blocking?, stream).  Every member of a
         communicator derives the same sub-sequence for it (issue order); bench.py prints it per rank at start-up."""
         pr, pc, pi, pj, nb = self.pr, self.pc, self.pi, self.pj, self.nb
         out = {"rank": self.rank, "world": self.world, "grid": [pr, pc], "coords": [pi, pj], "block": nb, "blocks": self.nbk,
-               "serial": self.serial,
+               "serial": self.serial, "storage": "packed lower by blocks",
                "row_communicator": [self.grank(pi, c) for c in range(pc)], "col_communicator": [self.grank(q, pj) for q in range(pr)],
                "hbm_plan_gb": {k: round(v / 1e9, 3) for k, v in self.plan.items()}, "steps": []}
         for K in range(min(steps, self.nbk)):
@@ -275,76 +324,66 @@ class DistFit:
 
     # ------------------------------------------------------------------ Gram build (no comm)
     def build(self):
-        """Each rank evaluates the pairs of its own blocks (inputs replicated, no collective).
-        Global block row I < N/nb holds q-rows of the points of point-block I, the others P-rows of
-        point-block I - N/nb; this rank's local rows are its q-type block rows followed by its P-type
-        ones.  When N/nb is a multiple of the grid dimension both halves select the SAME points and the
-        local matrix is again [[qq, qP], [Pq, PP]] over that selection (one kernel launch); otherwise the
-        four parts are built over their own selections (sgpr_gram_pairs_dev takes the parts one by one)."""
+        """Each rank evaluates the pairs of its own blocks ON OR BELOW the global block diagonal (inputs replicated, no
+        collective), column block by column block into the packed panels.  Global block row I < N/nb (per coordinate for
+        d > 1) holds the rows of one coordinate of the points of point-block I mod (N/nb); a column block belongs to one
+        coordinate and one point-block, the rows under it to several coordinates with their own point selections: one launch
+        per (column block, row coordinate) writes that part (sgpr_gram_pairs_dev takes the four parts of the one-pair layout
+        one by one, sgpr_gram_nd_sel_dev the blocks (a, b) of a selection)."""
         ops, nb, N = self.ops, self.nb, self.N
         nbN = N // nb
+        D = 2 * self.d
         dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to(ops.device)
-        sel = lambda blocks: (np.concatenate([np.arange(B * nb, (B + 1) * nb) for B in blocks])
-                              if blocks else np.zeros(0, dtype=np.int64))
-        ld = self.mloc
-        if self.X is not None:
-            # d pairs per point: global block row I belongs to coordinate a = I // (N/nb) and point-block I % (N/nb).
-            # When N/nb is a multiple of the grid dimension every coordinate block of this rank selects the same
-            # points (one launch writes all (2d)^2 blocks); otherwise the selections differ from coordinate to
-            # coordinate, and one launch per PAIR of distinct selections writes the blocks that belong to it.
-            D = 2 * self.d
+        sel = lambda blocks: np.concatenate([np.arange(B * nb, (B + 1) * nb) for B in blocks])
+        cache = {}
 
-            def groups(blocks):
-                """per coordinate: (tuple of point-blocks, local offset in blocks)"""
-                out, pos = [], 0
-                for a in range(D):
-                    mine = tuple(B - a * nbN for B in blocks if B // nbN == a)
-                    out.append((mine, pos))
-                    pos += len(mine)
-                return out
+        def pts(blocks):
+            """device copies of the coordinates of a selection of point-blocks (cached: the selections repeat from column to column)"""
+            key = tuple(blocks)
+            if key not in cache:
+                idx = sel(blocks)
+                if self.X is not None:
+                    cache[key] = (dev(np.asfortranarray(self.X[idx]).T.copy()).reshape(-1), None)   # (m x 2d) column-major, flat
+                else:
+                    cache[key] = (dev(self.x[idx]), dev(self.y[idx]))
+                if len(cache) > 4 * D + 8:
+                    cache.pop(next(iter(cache)))
+            return cache[key]
 
-            rg, cg = groups(self.rows), groups(self.cols)
-            for R in sorted(set(g[0] for g in rg if g[0])):
-                for Cc in sorted(set(g[0] for g in cg if g[0])):
-                    rsel, csel = sel(list(R)), sel(list(Cc))
-                    mi, mj = len(rsel), len(csel)
-                    Xb = dev(np.asfortranarray(self.X[rsel]).T.copy()).reshape(-1)   # (mi x 2d) column-major, flat
-                    Xa = dev(np.asfortranarray(self.X[csel]).T.copy()).reshape(-1)
-                    if all(g[0] == R for g in rg) and all(g[0] == Cc for g in cg):
-                        ops.gram_nd(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld)
-                    else:
-                        roff = [g[1] * nb if g[0] == R else -1 for g in rg]
-                        coff = [g[1] * nb if g[0] == Cc else -1 for g in cg]
-                        ops.gram_nd_sel(self.family, self.d, mi, mj, Xb, Xa, self.hyp, self.A, ld, roff, coff)
-        else:
-            rq, rP = sel([I for I in self.rows if I < nbN]), sel([I - nbN for I in self.rows if I >= nbN])
-            cq, cP = sel([J for J in self.cols if J < nbN]), sel([J - nbN for J in self.cols if J >= nbN])
-            nrq, ncq = len(rq), len(cq)
-            offs = [0, nrq, ncq * ld, nrq + ncq * ld]             # qq, Pq, qP, PP inside the local matrix
-            if np.array_equal(rq, rP) and np.array_equal(cq, cP):
-                xb, yb, xa, ya = dev(self.x[rq]), dev(self.y[rq]), dev(self.x[cq]), dev(self.y[cq])
-                ops.gram_pairs(self.family, nrq, ncq, xb, yb, xa, ya, self.hyp, self.A, offs, ld, L.G_ALL)
-            else:
-                parts = ((L.G_QQ, rq, cq), (L.G_PQ, rP, cq), (L.G_QP, rq, cP), (L.G_PP, rP, cP))
-                for k, (flag, rs, cs) in enumerate(parts):
-                    if len(rs) == 0 or len(cs) == 0:
-                        continue
+        part = {(0, 0): (0, L.G_QQ), (1, 0): (1, L.G_PQ), (0, 1): (2, L.G_QP), (1, 1): (3, L.G_PP)}
+        for lj, J in enumerate(self.cols):
+            lf = self.lifirst[lj]
+            if lf >= len(self.rows):
+                continue
+            b, Jb = J // nbN, J % nbN                          # the column's coordinate and point-block
+            ca = pts([Jb])
+            pos = 0                                            # row blocks of the panel written so far
+            for a in range(D):
+                mine = [I - a * nbN for I in self.rows[lf:] if I // nbN == a]
+                if not mine:
+                    continue
+                rb = pts(mine)
+                mi = len(mine) * nb
+                off = self.coloff[lj] + pos * nb
+                if self.X is not None:
+                    roff = [0 if aa == a else -1 for aa in range(D)]
+                    coff = [0 if bb == b else -1 for bb in range(D)]
+                    ops.gram_nd_sel(self.family, self.d, mi, nb, rb[0], ca[0], self.hyp, self.A[off:], self.ld[lj], roff, coff)
+                else:
+                    k, flag = part[(a, b)]
                     po = [None] * 4
-                    po[k] = offs[k]
-                    ops.gram_pairs(self.family, len(rs), len(cs), dev(self.x[rs]), dev(self.y[rs]), dev(self.x[cs]),
-                                   dev(self.y[cs]), self.hyp, self.A, po, ld, flag)
+                    po[k] = off
+                    ops.gram_pairs(self.family, mi, nb, rb[0], rb[1], ca[0], ca[1], self.hyp, self.A, po, self.ld[lj], flag)
+                pos += len(mine)
         # |sig2n| on the global diagonal: the diagonal blocks this rank owns
-        for li, I in enumerate(self.rows):
-            if I % self.pc == self.pj:
-                lj = I // self.pc
-                blk = self.A2[lj * nb:(lj + 1) * nb, li * nb:(li + 1) * nb]
-                blk.diagonal().add_(self.sig2n)
+        for K in self.owned:
+            self._blk(K // self.pr, K // self.pc).diagonal().add_(self.sig2n)
 
     # ------------------------------------------------------------------ factorisation
     def _buffers(self, K):
         """Operand buffers of panel K (two sets: panel K+1 is in flight while update K runs)."""
         if not hasattr(self, "_bufs"):
-            nb, mk = self.nb, lambda cnt: self.ops.empty(max(cnt, 1) * self.nb * self.nb)
+            mk = lambda cnt: self.ops.empty(max(cnt, 1) * self.nb * self.nb)
             per_q = [len([J for J in self.cols if J % self.pr == q]) for q in range(self.pr)]
             self._bufs = [{"row": mk(len(self.rows)), "col": mk(len(self.cols)), "stage": [mk(c) for c in per_q]}
                           for _ in range(2)]
@@ -357,8 +396,7 @@ class DistFit:
         kI, kJ = K % pr, K % pc
         lj_K = K // pc
         if (pi, pj) == (kI, kJ):
-            li_K = K // pr
-            blk = self.A2[lj_K * nb:(lj_K + 1) * nb, li_K * nb:(li_K + 1) * nb]
+            blk = self._blk(K // pr, lj_K)
             self.Lkk.view(nb, nb).copy_(blk)
             ops.potrf(nb, self.Lkk, self.wbuf, self.info_t)
             # LAPACK-style global index of the first failing minor, tracked on the device; a negative
@@ -367,7 +405,7 @@ class DistFit:
             cand = torch.where(i64 > 0, i64 + K * nb, torch.where(i64 < 0, i64, torch.full_like(i64, self._BIG)))
             self.fail_t = torch.minimum(self.fail_t, cand)
             blk.copy_(self.Lkk.view(nb, nb))
-            self.work[K] = self.wbuf.clone()          # (the whole workspace: the solves keep their hand-off words in it)
+            self.work[K].copy_(self.wbuf)             # (the whole workspace: the solves keep their hand-off words in it)
         li0 = _count_le(K, pi, pr)            # first local block row with I > K
         m_p = self.mloc - li0 * nb
         if pj == kJ:
@@ -377,13 +415,13 @@ class DistFit:
                 dist.broadcast(msg, src=src, group=self.col_groups[kJ])
                 self.comm_bytes += 8 * msg.numel() * (self.rank != src)
             if m_p > 0:
-                ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, li0 * nb + lj_K * nb * self.mloc, self.mloc)
+                ops.trsm(m_p, nb, self.Lkk, self.wbuf, self.A, self._off(li0, lj_K), self.ld[lj_K])
         nrow_blk = len(self.rows) - li0
         Lrow = self._buffers(K)["row"][:nrow_blk * nb * nb]
         handles = []
         if nrow_blk > 0:
-            if pj == kJ:
-                Lrow.view(nb, nrow_blk * nb).copy_(self.A2[lj_K * nb:(lj_K + 1) * nb, li0 * nb:])
+            if pj == kJ:                      # the solved rows of the panel, packed to leading dimension m_p (one launch)
+                ops.copy_blocks(m_p, nb, 1, self.A, self._off(li0, lj_K), self.ld[lj_K], 0, Lrow, 0, m_p, 0)
             if pc > 1:
                 h = dist.broadcast(Lrow, src=self.grank(pi, kJ), group=self.row_groups[pi], async_op=not self.serial)
                 if not self.serial:
@@ -423,8 +461,8 @@ class DistFit:
         handles, stages = [], []
         for (q, t_q, period, cnt, pos0, pstep) in plan:
             st = buf["stage"][q][:cnt * nb * nb]
-            if pi == q:
-                st.view(nb, cnt, nb).copy_(Lrow.view(nb, nrow_blk, nb)[:, pos0:pos0 + (cnt - 1) * pstep + 1:pstep, :])
+            if pi == q:                       # every pstep-th block of my row piece, packed (one launch)
+                self.ops.copy_blocks(nb, nb, cnt, Lrow, pos0 * nb, nrow_blk * nb, pstep * nb, st, 0, cnt * nb, nb)
             if pr > 1:
                 h = dist.broadcast(st, src=self.grank(q, self.pj), group=self.col_groups[self.pj], async_op=not self.serial)
                 if not self.serial:
@@ -434,16 +472,14 @@ class DistFit:
         return (lj0, ncol_blk, stages, buf), handles
 
     def _col_finish(self, state):
-        """Regroup the received blocks by local column: a handful of strided device copies (no index
-        tensors, no host sync)."""
+        """Regroup the received blocks by local column: one launch per source process row (no index tensors, no host sync)."""
         nb = self.nb
         lj0, ncol_blk, stages, buf = state
         if ncol_blk == 0:
             return None, 0, lj0
         Lcol = buf["col"][:ncol_blk * nb * nb]
-        Lc3 = Lcol.view(nb, ncol_blk, nb)      # [k, block, row in block]
         for (st, t_q, period, cnt) in stages:
-            Lc3[:, t_q::period, :] = st.view(nb, cnt, nb)
+            self.ops.copy_blocks(nb, nb, cnt, st, 0, cnt * nb, nb, Lcol, t_q * nb, ncol_blk * nb, period * nb)
         return Lcol, ncol_blk, lj0
 
     def _exchange(self, K):
@@ -461,22 +497,21 @@ class DistFit:
         return Lrow, nrow_blk, Lcol, ncol_blk, lj0
 
     def _update(self, K, opnd, c_from, c_to):
-        """A(I,J) -= L(I,K) L(J,K)^T on the local blocks with I > K and local column blocks
-        lj0 + c_from .. lj0 + c_to - 1 (tiles above the global diagonal are skipped)."""
+        """A(I,J) -= L(I,K) L(J,K)^T on the local blocks with I >= J > K of the local column blocks
+        lj0 + c_from .. lj0 + c_to - 1: one product per column block (its panel has its own leading dimension)."""
         if opnd is None:
             return
         Lrow, nrow_blk, Lcol, ncol_blk, lj0 = opnd
         c_to = min(c_to, ncol_blk)
-        if c_to <= c_from:
-            return
-        nb, pr, pc = self.nb, self.pr, self.pc
-        li0 = _count_le(K, self.pi, pr)
-        m, n_all = nrow_blk * nb, ncol_blk * nb
-        ncols = (c_to - c_from) * nb
-        # the column operand is (n_all x nb) column-major; rows c_from*nb.. are its sub-block
-        self.ops.syrk_update(m, ncols, nb, Lrow, m, Lcol[c_from * nb:], n_all, self.A,
-                             li0 * nb + (lj0 + c_from) * nb * self.mloc, self.mloc,
-                             nb, pr, li0 * pr + self.pi, pc, (lj0 + c_from) * pc + self.pj)
+        nb = self.nb
+        li0 = _count_le(K, self.pi, self.pr)
+        for c in range(c_from, c_to):
+            lj = lj0 + c
+            lf = self.lifirst[lj]                 # (>= li0: J > K)
+            m = (len(self.rows) - lf) * nb
+            if m > 0:
+                self.ops.gemm_nt(m, nb, nb, -1.0, Lrow, (lf - li0) * nb, nrow_blk * nb, Lcol, c * nb, ncol_blk * nb, 1.0,
+                                 self.A, self.coloff[lj], self.ld[lj])
 
     def factor(self):
         """Right-looking with one step of look-ahead: while the bulk of trailing update K runs,
@@ -522,9 +557,8 @@ class DistFit:
 
     # ------------------------------------------------------------------ solves
     def _diag_block(self, K):
-        li, lj = K // self.pr, K // self.pc
         nb = self.nb
-        self.Lkk.view(nb, nb).copy_(self.A2[lj * nb:(lj + 1) * nb, li * nb:(li + 1) * nb])
+        self.Lkk.view(nb, nb).copy_(self._blk(K // self.pr, K // self.pc))
         return self.Lkk
 
     def solve(self):
@@ -557,8 +591,8 @@ class DistFit:
                 m_p = self.mloc - li0 * nb
                 if m_p > 0:
                     # pend[rows I > K] += L(I,K) y_K   (gemv_sub subtracts: feed -y)
-                    ops.gemv_sub(0, m_p, nb, self.A, li0 * nb + (K // pc) * nb * self.mloc, self.mloc,
-                                 -vec, pend[li0 * nb:])
+                    lj = K // pc
+                    ops.gemv_sub(0, m_p, nb, self.A, self._off(li0, lj), self.ld[lj], -vec, pend[li0 * nb:])
         # backward: x_K = L_KK^-T (y_K - sum_{I>K} L(I,K)^T x_I)
         rows_t = torch.as_tensor(self.rows, device=b.device)
         for K in range(self.nbk - 1, -1, -1):
@@ -571,7 +605,8 @@ class DistFit:
                 if m_p > 0:
                     xloc = b2[rows_t[li0:]].reshape(-1).contiguous()
                     # vec -= L_panel^T xloc  -> vec = -(sum)
-                    ops.gemv_sub(1, m_p, nb, self.A, li0 * nb + (K // pc) * nb * self.mloc, self.mloc, xloc, vec)
+                    lj = K // pc
+                    ops.gemv_sub(1, m_p, nb, self.A, self._off(li0, lj), self.ld[lj], xloc, vec)
                 dist.reduce(vec, dst=owner, op=dist.ReduceOp.SUM, group=self.col_groups[kJ])
             if self.rank == owner:
                 vec.add_(b2[K])
@@ -588,6 +623,69 @@ class DistFit:
         self.alpha = b
         self.nll = float((0.5 * torch.dot(self.z, b) + logdet[0]).item())
         return b
+
+    def solve_rhs(self, B):
+        """X = L^-T L^-1 B for a block of right-hand sides B (n x nrhs; NumPy array or tensor, the same on every rank) against
+        the distributed factor: what the reference does with matmul(Kyinv, .) at every prediction
+        (python/05_tokamak/SympGPR/sympgpr.f90:72,85,121) when Kyinv cannot exist on one device.  Returns X (n x nrhs,
+        replicated) as a tensor on the ops' device.
+
+        The right-hand sides are kept as ROWS (B^T, nrhs x n column-major): block K of all of them is one contiguous piece, so a
+        block step exchanges the WHOLE block with one reduce to the owner of L_KK and one broadcast, as solve() does for one
+        vector; the local work is two matrix products per block step on the fp64 MFMA kernel (sgpr_gemm_nt_dev /
+        sgpr_gemm_nn_dev) and the owner's triangular solve with L_KK (sgpr_trsm_rlt_dev / sgpr_trsm_rl_dev)."""
+        ops, nb, pr, pc, pi, pj = self.ops, self.nb, self.pr, self.pc, self.pi, self.pj
+        Bt = torch.as_tensor(np.asarray(B, dtype=np.float64) if not torch.is_tensor(B) else B).to(ops.device)
+        if Bt.dim() == 1:
+            Bt = Bt.reshape(-1, 1)
+        if Bt.shape[0] != self.n:
+            raise ValueError("solve_rhs: B has %d rows, the factor is of order %d" % (Bt.shape[0], self.n))
+        m = int(Bt.shape[1])
+        # [n, m] row-major = (m x n) column-major with leading dimension m: the right-hand sides as rows
+        X = Bt.contiguous().clone().reshape(-1)
+        XK = lambda K: X[K * nb * m:(K + 1) * nb * m]            # block K of every right-hand side: (m x nb), contiguous
+        pend = ops.zeros(m * self.mloc)                          # (m x mloc): what the solved blocks contribute to my rows
+        vec = ops.empty(m * nb)
+        # forward: Y_K = (B_K - sum_{J<K} Y_J L(K,J)^T) L_KK^-T
+        for K in range(self.nbk):
+            kI, kJ = K % pr, K % pc
+            owner = self.grank(kI, kJ)
+            if pi == kI:
+                li_K = K // pr
+                vec.copy_(pend[li_K * nb * m:(li_K + 1) * nb * m])
+                dist.reduce(vec, dst=owner, op=dist.ReduceOp.SUM, group=self.row_groups[kI])
+            if self.rank == owner:
+                vec.neg_().add_(XK(K))
+                ops.trsm_rows(m, nb, self._diag_block(K), self.work[K], vec, 0, m, 0)
+            dist.broadcast(vec, src=owner, group=self.group)
+            XK(K).copy_(vec)
+            if pj == kJ:
+                li0 = _count_le(K, pi, pr)
+                m_p = self.mloc - li0 * nb
+                if m_p > 0:
+                    # pend[:, rows I > K] += Y_K L(I,K)^T
+                    lj = K // pc
+                    ops.gemm_nt(m, m_p, nb, 1.0, vec, 0, m, self.A, self._off(li0, lj), self.ld[lj], 1.0, pend, li0 * nb * m, m)
+        # backward: X_K = (Y_K - sum_{I>K} X_I L(I,K)) L_KK^-1
+        rows_t = torch.as_tensor(self.rows, device=X.device)
+        for K in range(self.nbk - 1, -1, -1):
+            kI, kJ = K % pr, K % pc
+            owner = self.grank(kI, kJ)
+            if pj == kJ:
+                vec.zero_()
+                li0 = _count_le(K, pi, pr)
+                m_p = self.mloc - li0 * nb
+                if m_p > 0:
+                    xloc = X.view(self.nbk, nb * m)[rows_t[li0:]].reshape(-1).contiguous()   # my rows of the solution so far, side by side
+                    lj = K // pc
+                    ops.gemm_nn(m, nb, m_p, -1.0, xloc, 0, m, self.A, self._off(li0, lj), self.ld[lj], 1.0, vec, 0, m)
+                dist.reduce(vec, dst=owner, op=dist.ReduceOp.SUM, group=self.col_groups[kJ])
+            if self.rank == owner:
+                vec.add_(XK(K))
+                ops.trsm_rows(m, nb, self._diag_block(K), self.work[K], vec, 0, m, 1)
+            dist.broadcast(vec, src=owner, group=self.group)
+            XK(K).copy_(vec)
+        return X.view(self.n, m)
 
     def _solve_status(self, nb, Lkk, work):
         """the strip solves bound their waits; a solve that gave up is reported through the solve's last reduction"""

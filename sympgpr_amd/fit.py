@@ -163,9 +163,17 @@ class SympFit:
     def solve_rhs_dev(self, dptr, nrhs, ldb=None):
         """solve_rhs for right-hand sides that are already on the fit's device: `dptr` = device address (int) of an n x nrhs
         column-major block of doubles -- e.g. `t.data_ptr()` of a contiguous torch.float64 tensor of shape (nrhs, n) --,
-        overwritten with the solution.  No host copies; returns when the solve has finished."""
+        overwritten with the solution.  No host copies; returns when the solve has finished.
+
+        The solve runs on the FIT'S OWN stream and is not ordered against the stream that produced the block: the caller makes
+        sure B is complete on the device before the call (e.g. `torch.cuda.current_stream().synchronize()`, as bench.py does).
+        The scratch of the block solves (~0.8 GB at n = 98 304) stays with the handle until `release_scratch()` or close."""
         L.check(self._lib.sgpr_fit_solve_rhs_dev(self._h, C.c_void_p(int(dptr)), self.n if ldb is None else int(ldb), int(nrhs)),
                 "sgpr_fit_solve_rhs_dev")
+
+    def release_scratch(self):
+        """give the block solves' device scratch back (it is allocated again by the next solve_rhs that needs it)"""
+        L.check(self._lib.sgpr_fit_trim(self._h), "sgpr_fit_trim")
 
     def solve_rhs_ms(self):
         """Device time (ms) of the last solve_rhs: the triangular solves without the host copies of B."""
@@ -180,6 +188,16 @@ class SympFit:
         L.check(self._lib.sgpr_fit_predict_rows(self._h, m, L.dptr(q), L.dptr(P), L.dptr(op), L.dptr(oq)),
                 "sgpr_fit_predict_rows")
         return op, oq
+
+    def cond_estimate(self, iters=30):
+        """cond_2(Ky) from below: power iteration for lambda_max (Ky v through the prediction kernel), inverse iteration with
+        the cached factor for lambda_min.  Returns dict(lambda_max, lambda_min, cond, last_change, iters).  Not part of the
+        reference's call surface (it never computes a condition number); the parity tolerances are multiples of cond * eps."""
+        o = np.zeros(4)
+        L.check(self._lib.sgpr_fit_cond_estimate(self._h, int(iters), L.dptr(o)), "sgpr_fit_cond_estimate")
+        return {"lambda_max": float(o[0]), "lambda_min": float(o[1]), "cond": float(o[2]), "last_change": float(o[3]),
+                "iters": int(iters), "method": "power iteration on Ky v (rows re-evaluated by the prediction kernel) / inverse "
+                                                "iteration with the cached factor; Rayleigh quotients: a lower bound of cond_2"}
 
     def stage_ms(self):
         b, f, s = C.c_double(), C.c_double(), C.c_double()

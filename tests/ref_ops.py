@@ -63,15 +63,23 @@ class RefOps:
         Bv = _mat(B, boff, m, nb, ldb)
         Bv[:, :] = scipy.linalg.solve_triangular(Lm, Bv.T, lower=True).T
 
-    def syrk_update(self, m, n, k, A, lda, B, ldb, Cm, coff, ldc, blk, pr, pi, pc, pj):
+    def gemm_nt(self, m, n, k, alpha, A, aoff, lda, B, boff, ldb, beta, Cm, coff, ldc):
         Cv = _mat(Cm, coff, m, n, ldc)
-        upd = _mat(A, 0, m, k, lda) @ _mat(B, 0, n, k, ldb).T
-        # same skip rule as the HIP kernel, at block granularity: blocks above the global
-        # diagonal are left alone (they are never read)
-        rb = (np.arange(m) // blk) * pr + pi
-        cb = (np.arange(n) // blk) * pc + pj
-        mask = rb[:, None] >= cb[None, :]
-        Cv[mask] -= upd[mask]
+        Cv[:, :] = beta * Cv + alpha * (_mat(A, aoff, m, k, lda) @ _mat(B, boff, n, k, ldb).T)
+
+    def gemm_nn(self, m, n, k, alpha, A, aoff, lda, B, boff, ldb, beta, Cm, coff, ldc):
+        Cv = _mat(Cm, coff, m, n, ldc)
+        Cv[:, :] = beta * Cv + alpha * (_mat(A, aoff, m, k, lda) @ _mat(B, boff, k, n, ldb))
+
+    def trsm_rows(self, m, nb, Lkk, work, B, boff, ldb, trans):
+        Lm = np.tril(_mat(Lkk, 0, nb, nb, nb))
+        Bv = _mat(B, boff, m, nb, ldb)
+        # rows of B are right-hand sides: B L^-T solves L x = b, B L^-1 solves L^T x = b
+        Bv[:, :] = scipy.linalg.solve_triangular(Lm, Bv.T, lower=True, trans=1 if trans else 0).T
+
+    def copy_blocks(self, rows, cols, cnt, src, soff, lds, sstep, dst, doff, ldd, dstep):
+        for i in range(cnt):
+            _mat(dst, doff + i * dstep, rows, cols, ldd)[:, :] = _mat(src, soff + i * sstep, rows, cols, lds)
 
     def trsv(self, nb, Lkk, work, b, trans):
         Lm = np.tril(_mat(Lkk, 0, nb, nb, nb))

@@ -27,11 +27,29 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libsympgpr_hip.so does not export " + s
 
 
+def test_library_exports_nothing_but_the_c_abi_and_the_probe_hooks():
+    """csrc/exports.map: the dynamic symbol table of libsympgpr_hip.so holds the C entry points of include/sympgpr_hip.h and the
+    internal entry points the measurement library shares state through (listed in the map) -- no other C++ internals"""
+    import subprocess
+    from sympgpr_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if " T " in ln or " W " in ln or " B " in ln or " D " in ln]
+    c_abi = sorted(n for n in names if n.startswith("sgpr_"))
+    assert c_abi == _header_symbols()
+    rest = [n for n in names if not n.startswith("sgpr_")]
+    hooks = open(os.path.join(ROOT, "sympgpr_amd", "csrc", "exports.map")).read()
+    stems = re.findall(r"sgpr::([A-Za-z_:]+)\*;", hooks)
+    assert stems and len(rest) <= len(stems) + 4, rest
+    for n in rest:
+        assert n.startswith("_ZN4sgpr"), n                      # mangled sgpr::...
+        assert any(st.split("::")[-1] in n for st in stems), n
+
+
 def test_ctypes_table_matches_header():
     from sympgpr_amd import _lib
     assert sorted(_lib.SIGNATURES) == _header_symbols()
     lib = _lib.load_library()
-    assert lib.sgpr_abi_version() == 4
+    assert lib.sgpr_abi_version() == 5
 
 
 def test_mirror_has_reference_call_surface():
@@ -158,10 +176,21 @@ def test_generated_kernels_are_up_to_date(tmp_path, monkeypatch):
     gk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gk)
     out = tmp_path / "pair_generated.h"
+    npz = tmp_path / "user_family.npz"
     monkeypatch.setattr(gk, "OUT", str(out))
+    monkeypatch.setattr(gk, "NPZ_OUT", str(npz))          # (the tracked fixture must not be rewritten by a test run)
+    golden = os.path.join(ROOT, "tests", "golden", "user_family.npz")
+    before = os.stat(golden).st_mtime_ns
     gk.main()
     committed = open(os.path.join(ROOT, "sympgpr_amd", "csrc", "generated", "pair_generated.h")).read()
     assert out.read_text() == committed
+    assert os.stat(golden).st_mtime_ns == before
+    import numpy as np
+    new, old = np.load(str(npz)), np.load(golden)
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if old[k].dtype.kind == "f":
+            np.testing.assert_allclose(new[k], old[k], rtol=1e-13, atol=1e-300)
 
 
 def test_bench_starts_its_own_ranks_before_touching_the_gpu(monkeypatch):

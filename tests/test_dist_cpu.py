@@ -137,6 +137,59 @@ def test_block_cyclic_not_pd_reports_same_info_everywhere():
     assert expect > 0 and infos == {expect}
 
 
+def _worker_rhs(rank, world, port, N, nb, nrhs, d, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SYMPGPR_NO_TORCH_PRELOAD"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sympgpr_amd.dist import DistFit
+        from tests.ref_ops import RefOps
+        rng = np.random.default_rng(4321)
+        X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
+        z = rng.standard_normal(2 * d * N)
+        B = rng.standard_normal((2 * d * N, nrhs))
+        B[:, 0] = z
+        hyp = np.append(np.full(2 * d, 1.1), 1.0)
+        if d == 1:
+            f = DistFit(RefOps(), "A", X[:, 0], X[:, 1], z, hyp[[0, 1, 2]], 0.05, nb=nb)
+        else:
+            f = DistFit(RefOps(), "A", None, None, z, hyp, 0.05, nb=nb, X=X)
+        a = f.run().numpy().copy()
+        Xs = f.solve_rhs(B).numpy().copy()
+        x1 = f.solve_rhs(B[:, 1]).numpy().copy()              # a single vector goes through the same path
+        out[rank] = (a, Xs, x1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,N,nb,nrhs,d", [(2, 24, 4, 5, 1), (4, 32, 4, 7, 1), (8, 64, 4, 3, 1), (6, 40, 4, 4, 1), (4, 16, 4, 6, 2)])
+def test_block_of_right_hand_sides_against_the_distributed_factor(oracle, world, N, nb, nrhs, d):
+    """DistFit.solve_rhs: X = Ky^-1 B for a block of right-hand sides kept as rows, one reduce + one broadcast of the whole
+    block per block step (SURVEY 8(e) "Solves"; what the reference's matmul(Kyinv, .) of sympgpr.f90:72,85,121 becomes when
+    the factor is spread over the grid).  Against a dense solve with the oracle's Ky, on grids with and without N / nb a
+    multiple of the grid dimensions; column 0 is z, so it must also equal alpha."""
+    out = mp.Manager().dict()
+    mp.spawn(_worker_rhs, args=(world, _free_port(), N, nb, nrhs, d, out), nprocs=world, join=True)
+    rng = np.random.default_rng(4321)
+    X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
+    z = rng.standard_normal(2 * d * N)
+    B = rng.standard_normal((2 * d * N, nrhs))
+    B[:, 0] = z
+    hyp = np.append(np.full(2 * d, 1.1), 1.0)
+    K = oracle.build_K_nd("A", X, X, hyp) if d > 1 else oracle.build_K("A", X[:, 0], X[:, 1], X[:, 0], X[:, 1], hyp[[0, 1, 2]])
+    Xr = np.linalg.solve(K + 0.05 * np.eye(K.shape[0]), B)
+    assert len(out) == world
+    for r in range(world):
+        a, Xs, x1 = out[r]
+        assert Xs.shape == Xr.shape and x1.shape == (Xr.shape[0], 1)
+        assert np.linalg.norm(Xs - Xr) <= 1e-11 * np.linalg.norm(Xr)
+        assert np.linalg.norm(Xs[:, 0] - a) <= 1e-12 * np.linalg.norm(a)
+        assert np.linalg.norm(x1[:, 0] - Xr[:, 1]) <= 1e-11 * np.linalg.norm(Xr[:, 1])
+
+
 def test_block_size_is_picked_to_divide():
     from sympgpr_amd.dist import DistFit
     assert DistFit._pick_nb(65536, 2048, 1) == 2048
@@ -227,16 +280,18 @@ def test_serial_mode_blocking_collectives(oracle, world, N, nb):
 
 
 def test_hbm_plan_of_the_multi_gpu_headline():
-    """BASELINE's "synthetic d=2 N=65536" (n = 262144, 550 GB) on 4 and 8 MI355X: every rank's plan -- local piece of Ky, two
-    sets of panel buffers, diagonal block + workspace -- fits 288 GB with room to spare, on 2 ranks it does not; the plan's
-    matrix bytes add up to 8 n^2 over the grid."""
+    """BASELINE's "synthetic d=2 N=65536" (n = 262144, 550 GB dense) on 2, 4 and 8 MI355X: with the packed lower block
+    storage every rank's plan -- local piece of Ky, two sets of panel buffers, diagonal block + workspaces -- fits 288 GB with
+    room to spare, ALSO on 2 ranks (SURVEY 8 preamble: "2 GPUs only with lower-triangle storage"); the plans' matrix bytes add
+    up to the lower block triangle."""
     from sympgpr_amd.dist import hbm_plan
     N, d, nb = 65536, 2, 2048
     n = 2 * d * N
-    for world, limit in ((8, 100e9), (4, 170e9)):
+    nbk = n // nb
+    for world, limit in ((8, 60e9), (4, 100e9), (2, 170e9)):
         plans = [hbm_plan(N, d, nb, world, r) for r in range(world)]
-        assert sum(p["matrix"] for p in plans) == 8 * n * n
+        assert sum(p["matrix"] for p in plans) == 8 * nb * nb * nbk * (nbk + 1) // 2
         assert max(p["total"] for p in plans) < limit < 288e9, (world, max(p["total"] for p in plans) / 1e9)
-        assert all(p["panel_buffers"] < 0.2 * p["matrix"] for p in plans)
-    assert hbm_plan(N, d, nb, 2, 0)["total"] > 270e9          # 275 GB of matrix alone: not on two
-    assert hbm_plan(65536, 1, 2048, 1, 0)["matrix"] == 8 * 131072**2
+        assert all(p["panel_buffers"] < 0.35 * p["matrix"] for p in plans)
+    one = hbm_plan(65536, 1, 2048, 1, 0)
+    assert one["matrix"] == 8 * 2048 * 2048 * 64 * 65 // 2

@@ -256,6 +256,35 @@ def test_fit_vs_oracle(oracle, fam, N):
     assert np.abs(Lh - L_o).max() <= 1e-11 * np.abs(L_o).max()
 
 
+@pytest.mark.parametrize("fam,d,N", [("A", 1, 700), ("C", 1, 500), ("A", 2, 160), ("C", 3, 90)])
+def test_cond_estimate_vs_eigenvalues(oracle, fam, d, N):
+    """sgpr_fit_cond_estimate (power iteration through the prediction kernel + inverse iteration with the factor) against the
+    eigenvalues of the oracle's Ky: both quotients are one-sided bounds, so the estimate must not exceed the true condition
+    number, and with 80 steps it is within a few per cent of it at these sizes."""
+    from sympgpr_amd.fit import SympFit
+    rng = np.random.default_rng(99 + N)
+    if d == 1:
+        q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
+        l = 2.0 * np.sqrt(12 * np.pi / N)
+        hyp, s2 = [l, l, 1.0], 1e-2 / l**2
+        K = oracle.build_K(fam, q, P, q, P, hyp, threads=4)
+        fit = SympFit(fam, q, P, z, hyp, s2)
+    else:
+        X = np.column_stack([rng.uniform(0, 2 * np.pi, (N, d)), rng.uniform(-3, 3, (N, d))])
+        z = rng.standard_normal(2 * d * N)
+        l = 2.0 * np.sqrt(12 * np.pi) * N ** (-1.0 / (2 * d))
+        hyp, s2 = np.append(np.full(2 * d, l), 1.0), 1e-2 / l**2
+        K = oracle.build_K_nd(fam, X, X, hyp)
+        fit = SympFit.pairs(fam, X, z, hyp, s2)
+    w = np.linalg.eigvalsh(K + s2 * np.eye(K.shape[0]))
+    with fit as f:
+        f.run()
+        c = f.cond_estimate(80)
+    assert c["lambda_max"] <= w[-1] * (1 + 1e-10) and c["lambda_max"] >= 0.98 * w[-1], (c, w[-1])
+    assert c["lambda_min"] >= w[0] * (1 - 1e-8) and c["lambda_min"] <= 1.3 * w[0], (c, w[0])
+    assert c["cond"] <= (w[-1] / w[0]) * (1 + 1e-8)
+
+
 def test_fit_refit_and_errors():
     """the optimiser loop re-runs the path with new hyper-parameters on a resident handle
     (01_pendulum/implicit/main.py:146-151); a non-PD Ky raises LinAlgError like SciPy."""
@@ -328,7 +357,10 @@ def _dist_worker(rank, world, port, backend, N, nb, out):
         l = 2.0 * np.sqrt(12 * np.pi / N)
         f = DistFit(HipOps(torch.device("cuda", 0)), "A", q, P, z, [l, l, 1.0], 1e-2 / l**2, nb=nb)
         a = f.run().cpu().numpy().copy()
-        out[rank] = (a, f.nll)
+        Bm = np.random.default_rng(77).standard_normal((2 * N, 9))
+        Bm[:, 0] = z
+        Xs = f.solve_rhs(Bm).cpu().numpy().copy()            # a block of right-hand sides against the distributed factor
+        out[rank] = (a, f.nll, Xs)
     finally:
         dist.destroy_process_group()
 
@@ -350,12 +382,17 @@ def test_block_cyclic_hip_ops(oracle, world, backend, N, nb):
     q, P, z = rng.uniform(0, 2 * np.pi, N), rng.uniform(-3, 3, N), rng.standard_normal(2 * N)
     l = 2.0 * np.sqrt(12 * np.pi / N)
     from sympgpr_amd.fit import SympFit
+    Bm = np.random.default_rng(77).standard_normal((2 * N, 9))
+    Bm[:, 0] = z
     with SympFit("A", q, P, z, [l, l, 1.0], 1e-2 / l**2) as f:
         a_ref, nll_ref = f.run().alpha(), f.nll()
+        X_ref = f.solve_rhs(Bm)
     for r in range(world):
-        a, nll = out[r]
+        a, nll, Xs = out[r]
         assert np.linalg.norm(a - a_ref) / np.linalg.norm(a_ref) < 1e-10
         assert nll == pytest.approx(nll_ref, rel=1e-11)
+        assert np.linalg.norm(Xs - X_ref) <= 1e-10 * np.linalg.norm(X_ref)
+        assert np.linalg.norm(Xs[:, 0] - a) <= 1e-12 * np.linalg.norm(a)
 
 
 # ---------------------------------------------------------------- the func.py mirror
@@ -679,6 +716,29 @@ def test_block_rhs_strips_streamed_in_pieces(ops, n, nrhs, piece):
     err = np.linalg.norm(X - Xr, axis=0) / np.linalg.norm(Xr, axis=0)
     assert err.max() < 1e-11, (n, nrhs, piece, err.max(), int(err.argmax()))
     assert np.array_equal(X, X2)
+
+
+@pytest.mark.parametrize("bad_pass", [0, 1])
+def test_block_rhs_give_up_in_an_earlier_pass_is_reported(ops, bad_pass):
+    """130 right-hand sides = three 64-column passes through the strip solves.  A hand-off that gives up in the first or second
+    pass (forced: the tunable raises the forward solve's give-up word in front of that pass) must still be on record when the
+    status is read after the LAST pass: the call fails, it does not return 0 with NaN columns (round-4 advice: every pass used
+    to clear the give-up words)."""
+    from sympgpr_amd import _lib as L
+    probe = L.load_probe_library()
+    n, nrhs = 1280, 130
+    rng = np.random.default_rng(7)
+    L0 = np.tril(rng.standard_normal((n, n))) / np.sqrt(n)
+    L0[np.diag_indices(n)] = 1.0 + rng.uniform(0, 1, n)
+    B = rng.standard_normal((n, nrhs))
+    L.check(probe.sgpr_probe_tune(b"trsm_force_giveup_pass", float(bad_pass)))
+    try:
+        with pytest.raises(L.SympGPRError):
+            ops.solve_cholesky(np.asfortranarray(L0), B)
+    finally:
+        L.check(probe.sgpr_probe_tune(b"trsm_force_giveup_pass", -1.0))
+    X = ops.solve_cholesky(np.asfortranarray(L0), B)          # and the next call is clean again
+    assert np.all(np.isfinite(X))
 
 
 # ---------------------------------------------------------------- d canonical pairs (BASELINE d = 2, 3)
