@@ -337,11 +337,15 @@ int sgpr_predict_reg_dev(int family, int m, const double *q, const double *P, in
  *   SGPR_MAP_EXPLICIT  P = p - Kstar(1,:).alpha at (q, p), no implicit solve and no first-guess GP
  *                      (01_pendulum/explicit/func_expl.py:106-128, 04_standard_map/func.py:174-179,
  *                      256-285); hypp / xtrainp / ytrainp / alphap are ignored
+ *   SGPR_MAP_LOSS_NEGP P < 0 after the implicit solve ends the orbit (the tokamak maps)
  * qmap, pmap: [nm][ntest] C-ordered; a NaN marks a lost orbit from that step on.  pdiff (may be
  * NULL): the unwrapped momentum, pdiff[i+1] = pdiff[i] + (P_new - p_i) (04_standard_map/func.py:234). */
 #define SGPR_MAP_WRAP_Q 1
 #define SGPR_MAP_WRAP_P 2
 #define SGPR_MAP_EXPLICIT 4
+#define SGPR_MAP_LOSS_NEGP 8   /* implicit map: an orbit whose new momentum P is negative is lost (NaN) from that step on -- the
+                                * tokamak drivers' loss test (05_tokamak/SympGPR/func.py:190-211, sympgpr.f90:128-177) without
+                                * its flux-surface half (fieldlines.compute_r stays with the caller).  ABI 5. */
 int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hyp, int nhyp, int n0,
                        const double *xtrain, const double *ytrain, const double *alpha,
                        const double *hypp, int nhypp, int n0p, const double *xtrainp,

@@ -10,7 +10,7 @@ K_DLX, K_DLY = 4, 8
 K_DX, K_DY, K_DX0, K_DY0, K_DXDX0DY0, K_DYDY0DY0, K_DXDY0DY0 = 16, 17, 18, 19, 20, 21, 22
 G_QQ, G_PQ, G_QP, G_PP, G_ALL, G_LOWER, G_OCML, G_DLX, G_DLY = 1, 2, 4, 8, 15, 16, 32, 64, 128
 FIT_LOWER_ONLY, FIT_REG, FIT_BLOCK_QQ, FIT_BLOCK_PP = 1, 4, 8, 16
-MAP_WRAP_Q, MAP_WRAP_P, MAP_EXPLICIT = 1, 2, 4
+MAP_WRAP_Q, MAP_WRAP_P, MAP_EXPLICIT, MAP_LOSS_NEGP = 1, 2, 4, 8
 E_ARG, E_NODEVICE, E_HIP, E_NOMEM, E_STATE = -1, -2, -3, -4, -5
 
 ABI_VERSION = 5      # include/sympgpr_hip.h: SGPR_ABI_VERSION

@@ -1219,7 +1219,7 @@ int sgpr_applymap_host(int family, int mode, int nm, int ntest, const double *hy
     if (rc) return rc;
     const bool expl = (mode & SGPR_MAP_EXPLICIT) != 0;
     if (expl) n0p = 0;                       /* no first-guess GP in the explicit map */
-    if (nm < 1 || ntest < 0 || n0 < 0 || n0p < 0 || (mode & ~7) || !qmap || !pmap) {
+    if (nm < 1 || ntest < 0 || n0 < 0 || n0p < 0 || (mode & ~15) || (expl && (mode & SGPR_MAP_LOSS_NEGP)) || !qmap || !pmap) {
         set_error("applymap: bad arguments");
         return SGPR_E_ARG;
     }

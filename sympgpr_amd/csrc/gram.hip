@@ -375,10 +375,17 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
     // (x, y) := sum over the team of every thread's (x, y), identical bits in every member: the workgroup's own sum first, then
     // ONE pair of granules per member, collected by lanes 0 .. S - 1.  (Tried: every wave publishing its own part, 4 S and 16 S
     // granule pairs to collect -- no gain at 256 threads, 40 instead of 65 G pair evaluations per second at 1024.)
+    __shared__ int sh_lost;
+    if (threadIdx.x == 0) sh_lost = 0;
+    __syncthreads();
     auto team_sum2 = [&](double &x, double &y) {
         ++seq;
         block_sum2<TT>(x, y, sh[seq & 1u]);
         if (S == 1) return;
+        if (lost) {                                     // sticky: one timeout ends the orbit, nobody waits 2 s per sum after it
+            x = y = __builtin_nan("");
+            return;
+        }
         if (threadIdx.x == 0) {
             unsigned long long *mine = a.tw + (((size_t)k * S + me) * 2 + (seq & 1u)) * 4;
             granule_store(mine, x, seq);
@@ -397,9 +404,10 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
             }
             sp[seq & 1u][0][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)u[1] << 32) | u[0])) : __builtin_nan("");
             sp[seq & 1u][1][threadIdx.x] = ok ? __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0])) : __builtin_nan("");
-            if (!ok) atomicExch(a.err, 1);
+            if (!ok) { atomicExch(a.err, 1); sh_lost = 1; }
         }
         __syncthreads();
+        lost = sh_lost != 0;                            // (block-uniform; sh_lost is only ever raised)
         double sx = 0.0, sy = 0.0;
         for (int m = 0; m < S; ++m) { sx += sp[seq & 1u][0][m]; sy += sp[seq & 1u][1][m]; }
         x = sx; y = sy;                                 // (no barrier behind the reads: the next call writes the other halves)
@@ -465,7 +473,6 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
         team_sum2(r, z);
         return r;
     };
-    (void)lost;
     double q = a.Q0[k], p = a.P0[k], pd = p;
     if (threadIdx.x == 0 && me == 0) {
         a.qmap[k] = q;
@@ -476,7 +483,10 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
     const double twopi = 6.283185307179586477;
     for (int i = 0; i + 1 < a.nm; ++i) {
         double qn = nan, pn = nan, pdn = nan;
-        if (!(q != q) && !(p != p)) {                      // NaN = lost orbit stays lost (func.py:231-232)
+        // some team of this call has given up (a.err): every member of every team sees it at its next step and writes NaN for
+        // the rest of its orbit instead of waiting for partners that have diverged
+        if (S > 1 && !lost && __hip_atomic_load((__attribute__((address_space(1))) int *)a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lost = true;
+        if (!lost && !(q != q) && !(p != p)) {             // NaN = lost orbit stays lost (func.py:231-232)
             double r1, r2, Praw = nan;
             bool have_r2 = false;
             if (a.mode & SGPR_MAP_EXPLICIT) {
@@ -505,6 +515,10 @@ __global__ __launch_bounds__(TT) void applymap_kernel(const MapArgs a)
                     have_r2 = true;                              // r2 belongs to (q, P1)
                 }
             }
+            // 05_tokamak/SympGPR/func.py:190-211, sympgpr.f90:128-177: an orbit whose new momentum is negative has left the
+            // plasma -- lost from this step on (the flux-surface half of that test needs the out-of-scope fieldlines module and
+            // stays with the caller: examples/tokamak.py)
+            if ((a.mode & SGPR_MAP_LOSS_NEGP) && Praw < 0.0) Praw = nan;
             if (Praw == Praw) {
                 pdn = pd + (Praw - p);                           // unwrapped momentum (04_standard_map/func.py:234)
                 pn = Praw;
@@ -690,7 +704,16 @@ int predict_rows(int family, int m, const double *q, const double *P, int n0, co
 // <= 170 VGPRs (3 waves per SIMD; family A, the largest, has 136).
 int applymap_team(int ntest, int n0)
 {
-    int S = ntest > 0 ? 512 / ntest : 1;
+    // resident workgroups the device can hold: two of these per CU (queried once per device; 256 CUs -> 512)
+    static const int slots = [] {
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) {
+            (void)hipGetLastError();
+            return 0;                                    // unknown device: no teams (S = 1 needs no co-residency)
+        }
+        return 2 * ncu;
+    }();
+    int S = ntest > 0 ? slots / ntest : 1;
     S = std::min(S, (n0 + MAP_TEAM_T - 1) / MAP_TEAM_T);
     return std::max(1, std::min(S, MAP_TEAM_MAX));
 }

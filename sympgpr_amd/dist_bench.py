@@ -100,7 +100,9 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
         torch.cuda.synchronize()
         L_.check(ops.lib.sgpr_profile_end(L_.dptr(prof)))
     # every rank's MFMA-kernel rate (all launches of its local trailing updates)
-    n_mine, fl_mine, ms_mine = prof[0] + prof[8], prof[1] + prof[9], prof[2] + prof[10]
+    # (launches of the 256 x 128 kernel, alone or overlapped, and of the 128 x 128 kernel small products go to: with the packed
+    # block storage a trailing update is one product per local column block)
+    n_mine, fl_mine, ms_mine = prof[0] + prof[3] + prof[8], prof[1] + prof[4] + prof[9], prof[2] + prof[5] + prof[10]
     mine = torch.tensor([fl_mine / (ms_mine * 1e-3) / 1e12 if ms_mine > 0 else 0.0], dtype=torch.float64, device=dev)
     ach_min, ach_max = mine.clone(), mine.clone()
     dist.all_reduce(ach_min, op=dist.ReduceOp.MIN)
@@ -158,10 +160,11 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
                                                       "process column + L_KK and its leaf inverses; a rank receives "
                                                       "(1/pr + 1/pc) of every panel"},
         }
-        n_l, fl, ms_l = prof[0] + prof[8], prof[1] + prof[9], prof[2] + prof[10]
+        n_l, fl, ms_l = n_mine, fl_mine, ms_mine
         if n_l > 0 and ms_l > 0:
             ach = fl / (ms_l * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> (rank 0's local trailing updates)",
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,128> / <128,128> (rank 0's local trailing updates, one product per column block)",
+                               "launches_256x128": int(prof[0] + prof[8]), "launches_128x128": int(prof[3]),
                                "achieved": ach, "peak": peaks["mfma"], "unit": "TFLOP/s", "frac": ach / peaks["mfma"],
                                "traffic": None, "traffic_source": None,
                                "timing": "one untimed extra step, HIP-event pair per launch on rank 0",

@@ -7,6 +7,7 @@ One recurrence, the variants the reference's drivers carry in their own func.py 
     applymap          04_standard_map/func.py:218-254     implicit, q and P mod 2 pi, + pdiff
     applymap_expl     04_standard_map/func.py:256-285     explicit, P mod 2 pi, + pdiff
     applymap          01_pendulum/explicit/func_expl.py:113-128   explicit, q mod 2 pi
+    applymap_tok      05_tokamak/SympGPR/func.py:182-211  implicit, q mod 2 pi, an orbit with P < 0 is lost (LOSS_NEGP)
 
 alpha = Kyinv ztrain is formed once (the reference re-multiplies Kyinv inside every calcP / calcQ
 call); a residual of the implicit equation is one block-wide reduction over the training points.
@@ -16,7 +17,7 @@ import numpy as np
 from . import _lib as L
 from .ops import get_family
 
-WRAP_Q, WRAP_P, EXPLICIT = L.MAP_WRAP_Q, L.MAP_WRAP_P, L.MAP_EXPLICIT
+WRAP_Q, WRAP_P, EXPLICIT, LOSS_NEGP = L.MAP_WRAP_Q, L.MAP_WRAP_P, L.MAP_EXPLICIT, L.MAP_LOSS_NEGP
 
 
 def run_map_alpha(mode, nm, Ntest, l, Q0map, P0map, xt, yt, alpha, hypp=None, xp=None, yp=None, alphap=None, family=None):

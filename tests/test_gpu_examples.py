@@ -171,6 +171,24 @@ def test_tokamak_maps_with_loss_test(oracle):
         np.testing.assert_allclose(p[i, ~lost], pr[i, ~lost], **TOL)
         np.testing.assert_allclose(q[i, ~lost], qr[i, ~lost], **TOL)
     assert lost.any() and (~lost).any()
+    # several steps per launch with the callback applied afterwards: the same map, bit for bit (orbits are independent)
+    q3, p3 = tk.applymap_tok(nm, Ntest, d["hyp"], d["hypp"], Q0, P0, d["xtrainp"], d["ztrainp"], d["Kyinvp"],
+                             d["xtrain"], d["ztrain"], d["Kyinv"], compute_r=compute_r, steps_per_launch=3)
+    assert np.array_equal(q3, q, equal_nan=True) and np.array_equal(p3, p, equal_nan=True)
+    # without a callback the whole map is ONE launch and only P < 0 loses an orbit (SGPR_MAP_LOSS_NEGP): start some orbits
+    # close to P = 0 so that the test bites
+    P0n = P0.copy()
+    P0n[::2] = 0.02
+    qrn, prn, _ = _ref_map(oracle, "A", d, nm, Q0, P0n, explicit=False, wrap_q=True, wrap_p=False)
+    qn, pn = tk.applymap_tok(nm, Ntest, d["hyp"], d["hypp"], Q0, P0n, d["xtrainp"], d["ztrainp"], d["Kyinvp"],
+                             d["xtrain"], d["ztrain"], d["Kyinv"])
+    lostn = np.zeros(Ntest, bool)
+    for i in range(1, nm):
+        lostn |= prn[i] < 0
+        assert np.all(np.isnan(pn[i, lostn])) and np.all(np.isnan(qn[i, lostn]))
+        np.testing.assert_allclose(pn[i, ~lostn], prn[i, ~lostn], **TOL)
+        np.testing.assert_allclose(qn[i, ~lostn], qrn[i, ~lostn], **TOL)
+    assert lostn.any() and (~lostn).any()
 
     # two sections with different GPs, alternating; nm = 8 leaves the last row untouched
     nm = 8
