@@ -939,6 +939,7 @@ __global__ __launch_bounds__(LT) void panel_batch_kernel(const PanelBatch q)
     a.inv = q.inv + (size_t)p * q.stride_inv + (size_t)(q.k0 / (int)LEAF) * LEAF * LEAF;
     a.dinfo = q.info + p; a.goff = q.k0;
     a.flags = q.flags + (size_t)p * PFLAG_STRIDE;
+    a.below_early = 1;            // (no helpers, no tiles here: a strip may only wait for smaller tickets, whatever the batch size)
     (void)panel_strip(a, g, s, sh);
 }
 
@@ -1294,6 +1295,8 @@ int queue_streams(QueueDevice &qd, int dev, int R, hipStream_t *sw, hipStream_t 
     return 0;
 }
 
+thread_local bool t_last_potrf_used_queue = false;   // set by potrf_queue once its kernels are enqueued, cleared by every potrf()
+
 // returns 1 when the queue form cannot be used here (the caller falls back to the look-ahead driver), < 0 on errors
 int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
 {
@@ -1362,6 +1365,7 @@ int potrf_queue(int n, double *A, size_t lda, const Ctx &c, int off0)
         ps.ver = ws.ver; ps.ver_ld = tn; ps.tver = ws.tver; ps.abort = cholq::abort_word(ws);
         ps.census = cholq::trace_panel_base((int)(plan->tasks.size() / 2));
         ps.helpers = q_helpers != 0; ps.tiles = q_tiles > 0;
+        t_last_potrf_used_queue = true;
         hipLaunchKernelGGL(panel_seq_kernel, dim3(pgrid), dim3(LT), 0, sp, ps);
         SGPR_CHECK_LAUNCH();
         if ((rc = cholq::launch_workers(*plan, ws, A, lda, inv_blk, flags_blk, c.dinfo, PFLAG_STRIDE, sw))) return rc;
@@ -1696,13 +1700,17 @@ int potrf_batch_panel(int nbatch, int npad, int k0, int Wd, double *A, size_t st
 // started there until the streams are released.  Returns true when the queue was in use (a retry will take the other driver).
 bool potrf_queue_mark_failed(hipStream_t st)
 {
+    // Did THIS thread's last factorisation go through the queue?  (Not "was the queue still on for the device": a give-up of
+    // the look-ahead driver's panel kernel at an order the queue never takes must not trigger a pointless second run, and two
+    // handles that give up in the same moment must both get their retry, whoever marks the device first.)
+    const bool used = t_last_potrf_used_queue;
+    if (!used) return false;
     int dev = -1;
     if ((st ? hipStreamGetDevice(st, &dev) : hipGetDevice(&dev)) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return false; }
     QueueDevice &qd = g_qdev[dev];
     std::lock_guard<std::mutex> lock(qd.mu);
-    const bool was_on = !qd.failed;
     qd.failed = true;
-    return was_on;
+    return true;
 }
 
 // the calling thread's pooled events (every device); call with no factorisation of this thread in flight
@@ -1740,6 +1748,7 @@ int potrf(int n, double *A, size_t lda, void *work, size_t lwork, int *dinfo, hi
     // blocks of order <= la_max go to the blocked look-ahead driver, larger ones split recursively
     // (SGPR_LA_MAX overrides; measured crossover of round 1)
     static const int la_max_env = [] { const char *e = getenv("SGPR_LA_MAX"); return e ? atoi(e) : 57344; }();
+    t_last_potrf_used_queue = false;
     Ctx c{static_cast<double *>(work), dinfo, st, mode == 1 ? 0 : la_max_env, flags};
     if (cholq::ws_bytes(n) > 0) c.qws = static_cast<char *>(work) + inv_bytes(n) + flag_bytes(n) + pub_bytes(n);
     const bool dbg = PANEL_DBG && getenv("SGPR_PANEL_DBG") != nullptr;

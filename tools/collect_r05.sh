@@ -21,7 +21,7 @@ for f in bench_n131072 bench_n16384 bench_henon_d2_n131072 bench_tokamak_d3_n983
     [ -f $S/${f}_kernel_stats.csv ] && cp $S/${f}_kernel_stats.csv $D/
     for g in $f ${f}_under_rocprof; do [ -f $S/$g.json ] && grep '^{' $S/$g.json | tail -1 > $D/$g.json; done
 done
-for f in rhs_sizes.txt potrf_sizes.txt solve_sizes.txt agent_info.csv map_rate.md potrf_q_vs_la.log probe_leaf.txt probe_lat.txt gemm_k.txt \
+for f in panel_stress.txt rhs_sizes.txt potrf_sizes.txt solve_sizes.txt agent_info.csv map_rate.md potrf_q_vs_la.log probe_leaf.txt probe_lat.txt gemm_k.txt \
          pmc_fetch_write_summary_n131072.txt launches_n131072.json; do [ -f $S/$f ] && grep -v amdgpu.ids $S/$f > $D/$f; done
 [ -f $S/gemm_launches_n131072.txt ] && grep -v amdgpu.ids $S/gemm_launches_n131072.txt > $D/gemm_launches_n131072.txt
 for g in $S/bench_batch_*.json; do [ -f $g ] && grep '^{' $g | tail -1 > $D/$(basename $g); done
