@@ -1546,7 +1546,8 @@ int potrf_lookahead(int n, double *A, size_t lda, const Ctx &c, int nb, int off0
             // strips below finish ~20 us after the last leaf.
             const double m_u2 = (double)(rows + w);                    // order of the update running beside
             const double u2_us = k > 0 ? m_u2 * m_u2 * (starts[k] - starts[k - 1]) / 55e6 : 0.0;
-            const bool split = nbelow > 0 && k > 0 && u2_us > 3.0 * (125.0 * pa.W + 100.0);
+            static const double split_ratio = tune("panel_split_ratio", 3.0);
+            const bool split = nbelow > 0 && k > 0 && u2_us > split_ratio * (125.0 * pa.W + 100.0);
             if (split) {
                 pa.R = pa.W;
                 pa.G = pa.W;

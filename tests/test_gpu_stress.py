@@ -115,6 +115,29 @@ def test_multiples_of_128_factor_and_solve(n):
     assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(b) * np.linalg.cond(A)
 
 
+@pytest.mark.parametrize("nb,knobs", [(1024, {}), (2048, {}), (1024, {"panel_tile_mult": 3}), (512, {"panel_helpers": 0}),
+                                      (1024, {"panel_tiles": 0}), (2048, {"panel_tiles": 0, "panel_below_early": 0})])
+def test_wide_panels_with_helpers_and_tiles(nb, knobs):
+    """The round-5 pieces of the persistent panel kernel at panel widths the default schedule reaches only at large orders:
+    8 and 16 leaf columns per panel = 21 / 105 helper workgroups for the tiles inside the diagonal block (claimed at run time),
+    the rows below drawn tile by tile from a counter by more or fewer workgroups than tiles, and each piece switched off in
+    turn.  The block width and the tunables are read once per process, so every case is a process of its own
+    (tools/potrf_modes.py: factor + solve + residual of Ky alpha = z through the prediction kernel, on n = 4096 and 6144)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SGPR_POTRF_NB=str(nb), SGPR_POTRF_Q="0")
+    cmd = [sys.executable, os.path.join(root, "tools", "potrf_modes.py")] + ["%s=%s" % kv for kv in knobs.items()] + ["2048", "3072"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("mode=")]
+    assert len(lines) == 2, r.stdout[-1500:]
+    for l in lines:
+        assert "nb=%d" % nb in l
+        assert float(l.split("resid")[1]) < 2e-12, l
+
+
 def test_three_threads_three_handles_order_16384(oracle):
     """Forward progress with concurrent handles at the size where the panels are wide (n = 16384: 1024- and 512-wide
     panels, up to 31 persistent workgroups each holding a CU): three threads factor three different problems at once,
