@@ -108,6 +108,32 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
     dist.all_reduce(ach_min, op=dist.ReduceOp.MIN)
     dist.all_reduce(ach_max, op=dist.ReduceOp.MAX)
 
+    # a block of right-hand sides against the distributed factor (DistFit.solve_rhs; config 05_tokamak's multi-RHS predict when the
+    # factor is spread over the grid) -- outside `value`, collective, and never fatal for the line: an error is reported as text
+    nrhs = args.nrhs if getattr(args, "nrhs", -1) >= 0 else (64 if d == 3 else 16)
+    rhs = None
+    if nrhs > 0:
+        STAGE[0] = "block of right-hand sides against the distributed factor"
+        try:
+            Bm = np.random.default_rng(5).standard_normal((n, nrhs))
+            Bm[:, 0] = z
+            Bt = torch.as_tensor(Bm).to(dev)
+            barrier()
+            t0 = time.perf_counter()
+            Xs = fit.solve_rhs(Bt)
+            barrier()
+            t_rhs = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t_rhs, op=dist.ReduceOp.MAX)
+            x0 = Xs[:, 0].contiguous()
+            al = fit.alpha
+            rhs = {"nrhs": nrhs, "ms": float(t_rhs.item()) * 1e3,
+                   "column0_vs_alpha": float((torch.linalg.norm(x0 - al) / torch.linalg.norm(al)).item()),
+                   "note": "wall time of DistFit.solve_rhs, max over ranks: 2 n / nb block steps, each one reduce + one broadcast of "
+                           "nrhs x nb doubles and two local MFMA products"}
+            del Xs, Bt
+        except Exception as e:                 # (a collective failure here would hang the other ranks: the 5-minute timeout ends them)
+            rhs = {"nrhs": nrhs, "error": "%s: %s" % (type(e).__name__, e)}
+
     # parity evidence: residual of Ky alpha = z on a sample of rows, rebuilt from the inputs
     a = fit.alpha.cpu().numpy()
     resid = None
@@ -176,6 +202,8 @@ def run_distributed(args, rank, local_rank, world, synth, metric, peaks, synth_p
                                "achieved": chol_flop / (stage[1] * 1e-3) / 1e12 / world, "peak": peaks["mfma"],
                                "unit": "TFLOP/s per GPU (factor stage incl. RCCL panel broadcasts)",
                                "frac": chol_flop / (stage[1] * 1e-3) / 1e12 / world / peaks["mfma"], "traffic": None}
+        if rhs is not None:
+            out["solve_rhs_distributed"] = rhs
         if cpu_baseline is not None and getattr(args, "cpu_sample", 0) > 0:
             # the same bounded CPU sample as the one-GPU line (rank 0 only; the other ranks wait at the barrier)
             cbl, _, _ = cpu_baseline(args.family if d == 1 else "A", args.cpu_sample)

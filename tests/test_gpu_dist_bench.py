@@ -53,3 +53,5 @@ def test_bench_three_ranks_two_pairs_per_point_on_one_card():
     assert d["residual_Ky_alpha_minus_z"] < 1e-10
     assert 0.0 < d["roofline"]["frac"] <= 1.0
     assert d["rccl_world_size"] == 3 and sorted(x["rank"] for x in d["ranks"]) == [0, 1, 2]
+    # the block of right-hand sides against the distributed factor: column 0 is z, so it reproduces alpha
+    assert d["solve_rhs_distributed"]["nrhs"] == 16 and d["solve_rhs_distributed"]["column0_vs_alpha"] < 1e-11, d["solve_rhs_distributed"]
