@@ -116,7 +116,38 @@ def cpu_baseline(family, n_pts_sample):
                                                   "two_solves_seconds": ts1}
     except Exception as e:
         variants["factor_solve_1_blas_thread"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the host (nproc, CPU model, BLAS), the two smaller sizes of the plan, and the full-size figures
+    # EXTRAPOLATED from the n = 16384 sample (build ~ n^2, factor ~ n^3) -- labelled as such
+    host = {"nproc": os.cpu_count()}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            host["cpu_model"] = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), None)
+    except OSError:
+        host["cpu_model"] = None
+    try:
+        from threadpoolctl import threadpool_info
+        host["blas"] = [{k: p.get(k) for k in ("internal_api", "version", "num_threads", "threading_layer")} for p in threadpool_info()
+                        if p.get("user_api") == "blas"]
+    except Exception:
+        host["blas"] = None
+    sizes = {}
+    for ns in (512, 2048):
+        try:
+            qs_, Ps_, zs_, hs_, s2s_ = synth(ns)
+            m_ = 2 * ns
+            t0 = time.perf_counter()
+            Ks = Ref().build_K(family, qs_, Ps_, qs_, Ps_, hs_) if kind == "reference" else Oracle().build_K(family, qs_, Ps_, qs_, Ps_, hs_, threads=1)
+            tb_ = time.perf_counter() - t0
+            Ks[np.diag_indices(m_)] += abs(s2s_)
+            t0 = time.perf_counter()
+            scipy.linalg.cholesky(Ks, lower=True, overwrite_a=True, check_finite=False)
+            tc_ = time.perf_counter() - t0
+            sizes["n=%d" % m_] = {"build_seconds_1_thread": tb_, "build_gb_s": 8.0 * m_ * m_ / tb_ / 1e9, "cholesky_seconds": tc_,
+                                  "cholesky_gflops": m_**3 / 3.0 / tc_ / 1e9}
+        except Exception as e:
+            sizes["n=%d" % (2 * ns)] = {"error": "%s: %s" % (type(e).__name__, e)}
     return {
+        "host": host, "smaller_sizes": sizes,
         "value": (n**3 / 3.0) / total / 1e12, "unit": "TFLOP/s", "cores": int(blas_threads),
         "kind": kind,
         "sample": "n=%d (N=%d pts): build_K 1 thread %.2fs = %.3f GB/s; scipy cholesky %d threads %.2fs = "
@@ -535,6 +566,12 @@ def main():
             out["alpha_rel_err_cond_estimate"] = cond_s2
             out["alpha_rel_err_d1_family_A"] = err1
             out["alpha_rel_err_d1_family_A_at"] = "n=%d vs the CPU baseline's solve" % (2 * args.cpu_sample)
+        n_s = 2 * args.cpu_sample
+        cb["extrapolated_to_full_size"] = {
+            "order_n": n, "from": "the n = %d sample above: build ~ n^2 (1 thread), cholesky ~ n^3 (%d BLAS threads)" % (n_s, cb["cores"]),
+            "build_seconds": (8.0 * n_s * n_s / cb["gram_gb_s"] / 1e9) * (n / n_s) ** 2,
+            "cholesky_seconds": ((n_s**3 / 3.0) / cb["chol_tflops"] / 1e12) * (n / n_s) ** 3,
+            "label": "EXTRAPOLATED, not measured"}
         out["cpu_baseline"] = cb
         # the checker's second job: rows of Ky at full size re-evaluated on the host by the oracle
         # (restated Fortran formulas), so the full-size residual does not rest on any device formula
